@@ -1,0 +1,143 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Msamples/s on data/scene.obj, 1920x1080 @ 256 spp per GPU (BASELINE.json configs[1]).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step is one pass of the hot path over one frame: every pixel's `samples` paths are traced, accumulated
+in sample order and tonemapped (src/Lib.hs:68-137).  The scene is already resident in HBM when the timed
+region starts.  With N ranks the frame is 1080p at 256*N spp (per-GPU work fixed => weak scaling): rows
+are sharded in interleaved blocks of 8, each rank renders its rows on its GPU and one RCCL all_gather
+reassembles the RGB8 framebuffer inside the timed region.  Msamples/s does not depend on spp.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def alg_bytes(c, spp):
+    """per ray N_branch*16 B + N_tri*40 B + N_hit*32 B, per pixel 12 B + 3 B."""
+    per_sample = (c["branch_visits"] * 16 + c["tri_tests"] * 40 + c["hits"] * 32) / c["samples"]
+    return per_sample + 15.0 / spp
+
+
+def cpu_baseline(w, h, spp, budget_rows):
+    """The oracle (kind 'port': C restatement of the reference CPU algorithm; GHC cannot run here) timed on
+    all host cores over a bounded sample of the same frame: every (w // budget_rows)-th row at full spp."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle as O
+    data = os.path.join(ROOT, "data")
+    ob = O.BIH(O.tris_from_obj(os.path.join(data, "scene.obj"), data))
+    cam = O.load_camera(os.path.join(data, "camera"))
+    cores = os.cpu_count() or 1
+    step = max(1, w // budget_rows)
+    t0 = time.time()
+    _, _, cnt = ob.render(cam, spp, w, h, threads=cores, rows=(step // 2, w), row_step=step, want_avg=False)
+    dt = time.time() - t0
+    rows = len(range(step // 2, w, step))
+    return {"value": round(cnt["samples"] / dt / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": f"{rows} rows (every {step}th) of the {w}x{h} @ {spp} spp frame = {cnt['samples']} samples in {dt:.1f} s"}, cnt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=1920)      # first dimension = image ROWS (src/Lib.hs:70-71)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=256)
+    ap.add_argument("--cpu-rows", type=int, default=8, help="rows of the frame timed on the CPU oracle")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    sqt = importlib.import_module("squigly-trace_amd")
+    d = importlib.import_module("squigly-trace_amd.dist")
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    data = os.path.join(ROOT, "data")
+    bih = sqt.BIH(sqt.Mesh.from_obj(os.path.join(data, "scene.obj"), data))
+    cam = sqt.load_camera(os.path.join(data, "camera"))
+    scene = sqt.DeviceScene(bih, local_rank)                 # resident in HBM before the timed region
+    w, h = args.width, args.height
+    spp = args.spp * world                                   # weak scaling: 256 spp of work per GPU
+
+    def step():
+        return d.render_frame(scene, cam, spp, w, h, want="rgb")
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    scene.reset_timing()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        frame = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kern_ms, launches, kname = scene.kernel_timing()
+    samples_per_step = w * h * spp                           # all ranks together
+    value = samples_per_step * args.steps / elapsed / 1e6
+
+    if rank == 0:
+        out = {
+            "metric": "Msamples/s (whole node) at 1080p/256spp on data/scene.obj",
+            "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "data/scene.obj + data/scene.sq + data/camera (the reference's sample scene)",
+            "config": {"workload": f"data/scene.obj {w}x{h} @ {args.spp} spp per GPU "
+                                   f"(one {w}x{h} frame at {spp} spp, rows sharded over {world} GPU(s), RGB8 all_gather)",
+                       "samples_per_step": samples_per_step, "row_block": d.ROW_BLOCK,
+                       "nonblack_pixels": int((frame.sum(-1) > 0).sum().item())},
+        }
+        cnt = None
+        if not args.no_cpu:
+            out["cpu_baseline"], cnt = cpu_baseline(w, h, args.spp, args.cpu_rows)
+        if cnt is not None and launches:
+            b = alg_bytes(cnt, args.spp)
+            per_launch_samples = samples_per_step / world    # one launch renders this rank's rows
+            achieved = b * per_launch_samples / (kern_ms * 1e-3) / 1e9
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+            if os.path.exists(tpath):
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                               "kernel": kname, "kernel_ms": round(kern_ms, 3), "launches": launches,
+                               "alg_bytes_per_sample": round(b, 1)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    scene.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,93 @@
+/* squigly_hip.h — C-ABI of libsquigly_hip.so: the MI355X drop-in for squigly-trace's
+ * per-pixel sampling loop.
+ *
+ * The reference (rrruko/squigly-trace) has no FFI.  Its hot path sits behind
+ *     render :: Scene a -> Camera -> Settings -> IO ()            (src/Lib.hs:68-75)
+ * and the narrowest seam is src/Lib.hs:73-74,
+ *     img = computeAs S (makeArray Par (w :. h) (renderPixel scene cam samples cast dims))
+ * i.e. "fill a w-rows x h-columns buffer of Pixel RGB Word8".  sq_render_rgb8() below is
+ * what a `foreign import ccall safe` at that line binds (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *  - plain C, no exceptions, no ownership transfer.  Every function returns 0 on success,
+ *    non-zero on failure; sq_last_error() then holds a message (thread-local).
+ *  - all input arrays are caller-owned, read-only, valid for the duration of the call.
+ *  - nothing is written to an output buffer on failure.
+ *  - there is NO CPU fallback: without a usable HIP device every render entry point fails.
+ *  - citations are relative to the reference repository root.
+ */
+#ifndef SQUIGLY_HIP_H
+#define SQUIGLY_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SQ_ABI_VERSION 1
+
+/* ---- data model (kept from the reference) ---- */
+typedef struct { float lo[3], hi[3]; } sq_bounds;            /* Bounds, src/Geometry.hs:153 */
+
+/* One BIH tree node, nodes stored in PRE-ORDER (a branch's left child is the next node).
+ * Tree a b / BIHNode, src/BIH.hs:26,37-40.
+ *   kind & 3 : 0,1,2 = Branch splitting on X,Y,Z ; 3 = Leaf
+ *   branch   : lmax, rmin = BIHN payload ; link = index of the RIGHT child
+ *   leaf     : link = index of its first triangle in `tris` (BIH.flatten order, src/BIH.hs:50-52);
+ *              kind >> 2 = number of triangles (0 allowed: src/BIH.hs:70-75) */
+typedef struct { int32_t kind; float lmax, rmin; int32_t link; } sq_node;
+
+typedef struct { float v0[3], v1[3], v2[3]; int32_t mat; } sq_tri;          /* Triangle, src/Geometry.hs:49-54 (material by index) */
+typedef struct { float reflective, surf[3], emissive, emit[3]; } sq_material; /* Material, src/Color.hs:78-83 */
+typedef struct { float pos[3]; float rot[9]; } sq_camera;    /* Camera, src/Geometry.hs:41; rot row-major = rotMatrixRads a b g (:90-102) */
+
+typedef struct {
+    sq_bounds          root;      /* bounds of BIH, src/BIH.hs:42 */
+    const sq_node*     nodes;     int32_t n_nodes;
+    const sq_tri*      tris;      int32_t n_tris;    /* leaf order */
+    const sq_material* mats;      int32_t n_mats;
+    int32_t            height;    /* BIH.height, src/BIH.hs:46-48 (sizes the traversal stack); 0 = compute */
+} sq_scene;
+
+/* ---- one-shot drop-in for src/Lib.hs:73-74 ---- */
+/* out: w*h*3 bytes, row-major, w ROWS x h COLUMNS (massiv `w :. h`, src/Lib.hs:70-71,80), RGB8 =
+ * rgbFloatToPixelRGB of each pixel (src/Lib.hs:93-104).  cast != 0 selects raycast (src/Lib.hs:141-151). */
+int sq_render_rgb8(const sq_scene* scene, const sq_camera* cam, int32_t samples, int32_t w, int32_t h,
+                   int32_t cast, uint8_t* out);
+/* out_avg: w*h*3 floats = the pre-tonemap `avg` of src/Lib.hs:88 (for tolerance checks). */
+int sq_render_f32(const sq_scene* scene, const sq_camera* cam, int32_t samples, int32_t w, int32_t h,
+                  int32_t cast, float* out_avg);
+
+/* ---- resident API: scene stays in HBM, output stays on the device (bench, multi-GPU) ---- */
+typedef struct sq_device_scene sq_device_scene;
+int  sq_scene_upload(const sq_scene* scene, int32_t device, sq_device_scene** out);
+void sq_scene_free(sq_device_scene* s);
+
+/* Row sharding (role of massiv's Par scheduler, src/Lib.hs:73): the w image rows are cut into
+ * blocks of `row_block` rows and block b belongs to shard (b % n_shards).  A shard renders its rows
+ * into a COMPACT buffer of sq_shard_rows() rows, local row j <-> global row sq_shard_global_row(). */
+typedef struct { int32_t row_block, shard, n_shards; } sq_shard;
+int32_t sq_shard_rows(int32_t w, sq_shard sh);
+int32_t sq_shard_global_row(int32_t local_row, sq_shard sh);
+
+/* d_avg (float, rows*h*3) and d_rgb (uint8, rows*h*3) are DEVICE pointers on the scene's device;
+ * either may be NULL.  hip_stream is a hipStream_t (NULL = the null stream); the call only enqueues
+ * work on it and returns (no synchronisation). */
+int sq_render_rows_device(sq_device_scene* s, const sq_camera* cam, int32_t samples, int32_t w, int32_t h,
+                          int32_t cast, sq_shard sh, float* d_avg, uint8_t* d_rgb, void* hip_stream);
+
+/* Timing of the dominant kernel measured with hipEvents on the stream it was launched on:
+ * average duration in ms over the launches since the last reset, and the launch count. */
+int  sq_kernel_timing(sq_device_scene* s, double* avg_ms, int64_t* launches, const char** kernel_name);
+void sq_kernel_timing_reset(sq_device_scene* s);
+/* Tunables (0 = library default). variant selects a kernel implementation; all produce identical bits. */
+int  sq_set_option(sq_device_scene* s, const char* key, int64_t value);
+
+int32_t     sq_device_count(void);
+int32_t     sq_abi_version(void);
+const char* sq_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,45 @@
+/* squigly_host.h — host side ABOVE the render boundary, as a C-ABI.
+ *
+ * In the reference these are Haskell functions (src/Obj.hs, src/BIH.hs, src/Geometry.hs) that a
+ * Haskell host would keep calling unchanged.  No GHC exists in the build or GPU images, so the
+ * same functions are provided in C++ (squigly-trace_amd/csrc/sq_host.cpp) with identical
+ * arithmetic, and produce exactly the arrays that squigly_hip.h consumes.
+ * All citations are relative to the reference repository root.
+ */
+#ifndef SQUIGLY_HOST_H
+#define SQUIGLY_HOST_H
+#include "squigly_hip.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* A loaded triangle soup in loader order (Obj.trisFromObj, src/Obj.hs:49-58). */
+typedef struct sq_mesh sq_mesh;
+int  sq_mesh_from_obj(const char* obj_path, const char* mtl_dir, sq_mesh** out);   /* mtl_dir plays "./data/" of src/Obj.hs:52 */
+int  sq_mesh_from_text(const char* obj_text, size_t obj_len, const char* sq_text, size_t sq_len, sq_mesh** out);
+int  sq_mesh_from_arrays(const sq_tri* tris, int32_t n_tris, const sq_material* mats, int32_t n_mats, sq_mesh** out);
+int32_t sq_mesh_num_tris(const sq_mesh* m);
+int32_t sq_mesh_num_materials(const sq_mesh* m);
+const sq_tri*      sq_mesh_tris(const sq_mesh* m);
+const sq_material* sq_mesh_materials(const sq_mesh* m);
+void sq_mesh_free(sq_mesh* m);
+
+/* Obj.loadCamera (src/Obj.hs:60-70): "px py pz\nalpha beta gamma" -> position + rotMatrixRads. */
+int  sq_camera_from_file(const char* path, sq_camera* cam);
+int  sq_camera_from_text(const char* text, size_t len, sq_camera* cam);
+void sq_rot_matrix_rads(float alpha, float beta, float gamma, float out9[9]);     /* src/Geometry.hs:90-102 */
+
+/* BIH.makeBIH (src/BIH.hs:62-99) + flatten (:50-52) into the pre-order arrays of squigly_hip.h.
+ * The returned object owns the arrays; sq_bih_scene() fills an sq_scene that points into it. */
+typedef struct sq_bih sq_bih;
+int  sq_bih_build(const sq_mesh* mesh, sq_bih** out);
+void sq_bih_scene(const sq_bih* b, sq_scene* out);
+int32_t sq_bih_height(const sq_bih* b);        /* BIH.height       src/BIH.hs:46-48 */
+int32_t sq_bih_num_leaves(const sq_bih* b);    /* BIH.numLeaves    src/BIH.hs:54-56 */
+int32_t sq_bih_longest_leaf(const sq_bih* b);  /* BIH.longestLeaf  src/BIH.hs:58-60 */
+void sq_bih_free(sq_bih* b);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -112,6 +112,8 @@ def lib():
         C.c_void_p, C.c_void_p, C.POINTER(Counters)]
     L.sqo_render_rows.argtypes = [C.c_void_p, C.POINTER(Camera)] + [C.c_int] * 9 + [
         C.c_void_p, C.c_void_p, C.POINTER(Counters)]
+    L.sqo_render_rows_strided.argtypes = [C.c_void_p, C.POINTER(Camera)] + [C.c_int] * 10 + [
+        C.c_void_p, C.c_void_p, C.POINTER(Counters)]
     L.sqo_sample_radiance.argtypes = [C.c_void_p, C.POINTER(Camera)] + [C.c_int] * 8 + [C.POINTER(C.c_float)]
     _lib = L
     return L
@@ -218,13 +220,15 @@ class BIH:
         return h
 
     def render(self, cam: Camera, samples, w, h, cast=False, threads=1, trig=TRIG_CRD, rng_variant=0,
-               rows=None, want_avg=True, want_rgb=True):
-        """Lib.render minus the PNG write. Returns (avg[w,h,3] f32, rgb[w,h,3] u8, counters dict)."""
+               rows=None, row_step=1, want_avg=True, want_rgb=True):
+        """Lib.render minus the PNG write. Returns (avg[w,h,3] f32, rgb[w,h,3] u8, counters dict).
+        rows=(y0,y1) with row_step renders rows y0, y0+row_step, ... < y1 into a compact array."""
         y0, y1 = rows if rows is not None else (0, w)
-        avg = np.zeros((y1 - y0, h, 3), np.float32) if want_avg else None
-        rgb = np.zeros((y1 - y0, h, 3), np.uint8) if want_rgb else None
+        nrows = len(range(y0, y1, row_step))
+        avg = np.zeros((nrows, h, 3), np.float32) if want_avg else None
+        rgb = np.zeros((nrows, h, 3), np.uint8) if want_rgb else None
         c = Counters()
-        _check(lib().sqo_render_rows(self._h, C.byref(cam), samples, w, h, int(cast), y0, y1, threads, trig,
+        _check(lib().sqo_render_rows_strided(self._h, C.byref(cam), samples, w, h, int(cast), y0, y1, row_step, threads, trig,
                                      rng_variant, avg.ctypes.data if want_avg else None,
                                      rgb.ctypes.data if want_rgb else None, C.byref(c)))
         return avg, rgb, c.asdict()

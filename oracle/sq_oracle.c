@@ -570,35 +570,36 @@ void sqo_sample_radiance(const sqo_bih* b, const sqo_camera* cam, int n, int w, 
 }
 
 typedef struct {
-    const sqo_bih* b; const sqo_camera* cam; int n, w, h, cast, y0, y1, trig, rngv;
+    const sqo_bih* b; const sqo_camera* cam; int n, w, h, cast, y0, y1, ystep, trig, rngv;
     float* avg; uint8_t* rgb; int* next_row; pthread_mutex_t* mu; sqo_counters c;
 } job_t;
 static void* worker(void* arg) {                                                      /* role of massiv Par, Lib.hs:73-74 */
     job_t* j = (job_t*)arg;
     ctx_t cx = { j->b, j->trig, j->rngv, &j->c };
     for (;;) {
-        pthread_mutex_lock(j->mu); int y = (*j->next_row)++; pthread_mutex_unlock(j->mu);
+        pthread_mutex_lock(j->mu); int r = (*j->next_row)++; pthread_mutex_unlock(j->mu);
+        int y = j->y0 + r * j->ystep;
         if (y >= j->y1) break;
         for (int x = 0; x < j->h; x++) {
             V3 a = render_pixel_avg(&cx, j->cam, j->n, j->cast, j->w, j->h, y, x);
-            size_t off = ((size_t)(y - j->y0) * (size_t)j->h + (size_t)x) * 3;
+            size_t off = ((size_t)r * (size_t)j->h + (size_t)x) * 3;
             if (j->avg) { j->avg[off] = a.x; j->avg[off + 1] = a.y; j->avg[off + 2] = a.z; }
             if (j->rgb) sqo_tonemap(a, j->trig, j->rgb + off);
         }
     }
     return NULL;
 }
-int sqo_render_rows(const sqo_bih* b, const sqo_camera* cam, int n, int w, int h, int cast, int y0, int y1,
-                    int threads, int trig, int rngv, float* avg, uint8_t* rgb, sqo_counters* counters) {
+int sqo_render_rows_strided(const sqo_bih* b, const sqo_camera* cam, int n, int w, int h, int cast, int y0, int y1,
+                    int ystep, int threads, int trig, int rngv, float* avg, uint8_t* rgb, sqo_counters* counters) {
     if (!b || !cam) return fail("null scene/camera");
-    if (n <= 0 || w <= 0 || h <= 0 || y0 < 0 || y1 > w || y0 > y1) return fail("bad dimensions/samples");
+    if (n <= 0 || w <= 0 || h <= 0 || y0 < 0 || y1 > w || y0 > y1 || ystep < 1) return fail("bad dimensions/samples");
     if (threads < 1) threads = 1;
     if (threads > 256) threads = 256;
-    pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER; int next = y0;
+    pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER; int next = 0;
     job_t* jobs = (job_t*)calloc((size_t)threads, sizeof *jobs);
     pthread_t* th = (pthread_t*)calloc((size_t)threads, sizeof *th);
     for (int t = 0; t < threads; t++) {
-        job_t j = { b, cam, n, w, h, cast, y0, y1, trig, rngv, avg, rgb, &next, &mu, { 0 } };
+        job_t j = { b, cam, n, w, h, cast, y0, y1, ystep, trig, rngv, avg, rgb, &next, &mu, { 0 } };
         jobs[t] = j;
         if (threads == 1) worker(&jobs[t]); else pthread_create(&th[t], NULL, worker, &jobs[t]);
     }
@@ -612,6 +613,10 @@ int sqo_render_rows(const sqo_bih* b, const sqo_camera* cam, int n, int w, int h
     if (counters) *counters = tot;
     free(jobs); free(th);
     return 0;
+}
+int sqo_render_rows(const sqo_bih* b, const sqo_camera* cam, int n, int w, int h, int cast, int y0, int y1,
+                    int threads, int trig, int rngv, float* avg, uint8_t* rgb, sqo_counters* counters) {
+    return sqo_render_rows_strided(b, cam, n, w, h, cast, y0, y1, 1, threads, trig, rngv, avg, rgb, counters);
 }
 int sqo_render(const sqo_bih* b, const sqo_camera* cam, int n, int w, int h, int cast, int threads, int trig,
                int rngv, float* avg, uint8_t* rgb, sqo_counters* counters) {

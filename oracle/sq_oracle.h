@@ -103,6 +103,10 @@ int  sqo_render(const sqo_bih* b, const sqo_camera* cam, int samples, int w, int
 int  sqo_render_rows(const sqo_bih* b, const sqo_camera* cam, int samples, int w, int h, int cast,
                      int y0, int y1, int threads, int trig_mode, int rng_variant,
                      float* out_avg, uint8_t* out_rgb, sqo_counters* counters);
+/* rows y0, y0+ystep, ... (< y1); output rows are compact in that order */
+int  sqo_render_rows_strided(const sqo_bih* b, const sqo_camera* cam, int samples, int w, int h, int cast,
+                     int y0, int y1, int ystep, int threads, int trig_mode, int rng_variant,
+                     float* out_avg, uint8_t* out_rgb, sqo_counters* counters);
 /* one sample's radiance: raytrace (mkTFGen (n*(x+y*w)+k)) scene ray 0  (Lib.hs:84-87) */
 void sqo_sample_radiance(const sqo_bih* b, const sqo_camera* cam, int samples, int w, int h,
                          int y, int x, int k, int trig_mode, int rng_variant, float out3[3]);

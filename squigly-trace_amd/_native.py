@@ -1,0 +1,116 @@
+"""ctypes binding of libsquigly_hip.so (include/squigly_hip.h, include/squigly_host.h).
+
+There is no Python or CPU fallback for the render path: if the shared library is missing this
+module raises, and if no HIP device is usable the render entry points return an error.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsquigly_hip.so")
+
+# numpy mirrors of the C structs
+NODE_DTYPE = np.dtype([("kind", "<i4"), ("lmax", "<f4"), ("rmin", "<f4"), ("link", "<i4")])
+TRI_DTYPE = np.dtype([("v0", "<f4", 3), ("v1", "<f4", 3), ("v2", "<f4", 3), ("mat", "<i4")])
+MAT_DTYPE = np.dtype([("reflective", "<f4"), ("surf", "<f4", 3), ("emissive", "<f4"), ("emit", "<f4", 3)])
+assert NODE_DTYPE.itemsize == 16 and TRI_DTYPE.itemsize == 40 and MAT_DTYPE.itemsize == 32
+
+
+class Bounds(C.Structure):
+    _fields_ = [("lo", C.c_float * 3), ("hi", C.c_float * 3)]
+
+
+class Camera(C.Structure):
+    """Geometry.Camera: position + rotation matrix (row-major)."""
+    _fields_ = [("pos", C.c_float * 3), ("rot", C.c_float * 9)]
+
+
+class Scene(C.Structure):
+    _fields_ = [("root", Bounds), ("nodes", C.c_void_p), ("n_nodes", C.c_int32), ("tris", C.c_void_p),
+                ("n_tris", C.c_int32), ("mats", C.c_void_p), ("n_mats", C.c_int32), ("height", C.c_int32)]
+
+
+class Shard(C.Structure):
+    _fields_ = [("row_block", C.c_int32), ("shard", C.c_int32), ("n_shards", C.c_int32)]
+
+
+class SquiglyError(RuntimeError):
+    """Raised when a C-ABI call returns non-zero; carries sq_last_error()."""
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python squigly-trace_amd/build.py` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, sz = C.c_void_p, C.c_int32, C.c_size_t
+    L.sq_last_error.restype = C.c_char_p
+    L.sq_device_count.restype = i32
+    L.sq_abi_version.restype = i32
+    L.sq_render_rgb8.argtypes = [C.POINTER(Scene), C.POINTER(Camera), i32, i32, i32, i32, vp]
+    L.sq_render_f32.argtypes = [C.POINTER(Scene), C.POINTER(Camera), i32, i32, i32, i32, vp]
+    L.sq_scene_upload.argtypes = [C.POINTER(Scene), i32, C.POINTER(vp)]
+    L.sq_scene_free.argtypes = [vp]
+    L.sq_scene_free.restype = None
+    L.sq_shard_rows.argtypes = [i32, Shard]
+    L.sq_shard_rows.restype = i32
+    L.sq_shard_global_row.argtypes = [i32, Shard]
+    L.sq_shard_global_row.restype = i32
+    L.sq_render_rows_device.argtypes = [vp, C.POINTER(Camera), i32, i32, i32, i32, Shard, vp, vp, vp]
+    L.sq_kernel_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_char_p)]
+    L.sq_kernel_timing_reset.argtypes = [vp]
+    L.sq_kernel_timing_reset.restype = None
+    L.sq_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
+    # host side
+    L.sq_mesh_from_obj.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(vp)]
+    L.sq_mesh_from_text.argtypes = [C.c_char_p, sz, C.c_char_p, sz, C.POINTER(vp)]
+    L.sq_mesh_from_arrays.argtypes = [vp, i32, vp, i32, C.POINTER(vp)]
+    L.sq_mesh_num_tris.argtypes = [vp]
+    L.sq_mesh_num_materials.argtypes = [vp]
+    L.sq_mesh_tris.argtypes = [vp]
+    L.sq_mesh_tris.restype = vp
+    L.sq_mesh_materials.argtypes = [vp]
+    L.sq_mesh_materials.restype = vp
+    L.sq_mesh_free.argtypes = [vp]
+    L.sq_mesh_free.restype = None
+    L.sq_camera_from_file.argtypes = [C.c_char_p, C.POINTER(Camera)]
+    L.sq_camera_from_text.argtypes = [C.c_char_p, sz, C.POINTER(Camera)]
+    L.sq_rot_matrix_rads.argtypes = [C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float)]
+    L.sq_rot_matrix_rads.restype = None
+    L.sq_bih_build.argtypes = [vp, C.POINTER(vp)]
+    L.sq_bih_scene.argtypes = [vp, C.POINTER(Scene)]
+    L.sq_bih_scene.restype = None
+    for f in ("height", "num_leaves", "longest_leaf"):
+        getattr(L, "sq_bih_" + f).argtypes = [vp]
+        getattr(L, "sq_bih_" + f).restype = i32
+    L.sq_bih_free.argtypes = [vp]
+    L.sq_bih_free.restype = None
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise SquiglyError(lib().sq_last_error().decode(errors="replace"))
+
+
+EXPORTED_SYMBOLS = [
+    # include/squigly_hip.h
+    "sq_render_rgb8", "sq_render_f32", "sq_scene_upload", "sq_scene_free", "sq_shard_rows",
+    "sq_shard_global_row", "sq_render_rows_device", "sq_kernel_timing", "sq_kernel_timing_reset",
+    "sq_set_option", "sq_device_count", "sq_abi_version", "sq_last_error",
+    # include/squigly_host.h
+    "sq_mesh_from_obj", "sq_mesh_from_text", "sq_mesh_from_arrays", "sq_mesh_num_tris",
+    "sq_mesh_num_materials", "sq_mesh_tris", "sq_mesh_materials", "sq_mesh_free", "sq_camera_from_file",
+    "sq_camera_from_text", "sq_rot_matrix_rads", "sq_bih_build", "sq_bih_scene", "sq_bih_height",
+    "sq_bih_num_leaves", "sq_bih_longest_leaf", "sq_bih_free",
+]

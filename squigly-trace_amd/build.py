@@ -1,0 +1,48 @@
+"""Build libsquigly_hip.so (HIP kernels for gfx950 + host side) in-tree with hipcc.
+
+    python squigly-trace_amd/build.py [--force]
+
+The flags that matter for bit-exact parity with the CPU oracle:
+  -ffp-contract=off                               no FMA contraction (host and device)
+  -fhip-fp32-correctly-rounded-divide-sqrt        IEEE fp32 divide / sqrt on the device
+  no -ffast-math, denormals kept (hipcc default for gfx9)
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libsquigly_hip.so")
+SOURCES = ["sq_device.hip", "sq_host.cpp"]
+HEADERS = ["sq_math.h", "sq_error.h", "../../include/squigly_hip.h", "../../include/squigly_host.h"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+         "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math",
+         "-Wall", "-Wno-unused-function"]
+
+
+def hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def stale():
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, extra=()):
+    if not force and not stale():
+        return OUT
+    cmd = [hipcc()] + FLAGS + list(extra) + ["-x", "hip"] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", OUT]
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, extra=[a for a in sys.argv[1:] if a.startswith("-R") or a.startswith("-save")]))

@@ -1,0 +1,386 @@
+// sq_host.cpp — host side above the render boundary: .obj/.sq/camera loaders and the BIH
+// build + flatten, with the reference's arithmetic (include/squigly_host.h).
+//
+// Array-based and O(n log n): the reference's list code (`!!` indexing, src/Obj.hs:83-85) is
+// O(n^2) and cannot load the 1M-triangle configuration.  Tree shape, split planes and leaf
+// order are bit-identical to src/BIH.hs because they decide traversal tie-breaks.
+// Citations are relative to the reference repository root.
+#include "../../include/squigly_host.h"
+#include "sq_error.h"
+#include "sq_math.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using sq::f3;
+
+struct sq_mesh {
+    std::vector<sq_tri> tris;
+    std::vector<sq_material> mats;
+};
+
+// ----------------------------------------------------------------------------------------------
+// Text scanning.  The reference grammar is Parsec (src/Obj.hs:96-171); this scanner accepts and
+// rejects the same byte strings.  Malformed numbers, which the reference turns into lazy `read`
+// failures, are reported as errors up front.
+// ----------------------------------------------------------------------------------------------
+namespace {
+
+struct Scanner {
+    const char* s; size_t n; size_t i = 0;
+    Scanner(const char* p, size_t len) : s(p), n(len) {}
+    int peek() const { return i < n ? (unsigned char)s[i] : -1; }
+    static bool ws(int c) { return c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '\f' || c == '\v'; }
+    static bool digit(int c) { return c >= '0' && c <= '9'; }
+    static bool alnum(int c) { return digit(c) || (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z'); }
+    void skip_ws() { while (ws(peek())) ++i; }
+    // Parsec `string`: returns 0 on match, 1 on failure with nothing consumed, 2 on failure after consuming
+    int literal(const char* lit) {
+        for (size_t k = 0; lit[k]; ++k) {
+            if (peek() != (unsigned char)lit[k]) return k == 0 ? 1 : 2;
+            ++i;
+        }
+        return 0;
+    }
+    // fractional (src/Obj.hs:115-121): -?digit*(.digit*)? then `read`, which needs digits on both sides of '.'
+    bool number(float& out) {
+        std::string tok;
+        if (peek() == '-') { tok.push_back('-'); ++i; }
+        size_t a = 0, b = 0; bool dot = false;
+        while (digit(peek())) { tok.push_back((char)peek()); ++i; ++a; }
+        if (peek() == '.') { tok.push_back('.'); ++i; dot = true; }
+        while (digit(peek())) { tok.push_back((char)peek()); ++i; ++b; }
+        if (a == 0 || (dot && b == 0)) { sq_set_error("no parse for number '%s' at byte %zu", tok.c_str(), i); return false; }
+        out = std::strtof(tok.c_str(), nullptr);   // correctly rounded, like read/fromRational
+        return true;
+    }
+    bool vec3(float v[3]) {                          // src/Obj.hs:166-171
+        for (int k = 0; k < 3; ++k) { if (!number(v[k])) return false; skip_ws(); }
+        return true;
+    }
+    bool word(std::string& out) {                    // src/Obj.hs:129-130
+        out.clear();
+        while (peek() >= 0 && !ws(peek())) { out.push_back((char)peek()); ++i; }
+        if (out.empty()) { sq_set_error("expected a word at byte %zu", i); return false; }
+        skip_ws();
+        return true;
+    }
+};
+
+struct ObjObject { std::string mtl; size_t face_begin, face_end; };
+struct ObjFile {
+    std::string mtllib;
+    std::vector<f3> verts;                 // all objects' vertices, concatenated (src/Obj.hs:76)
+    std::vector<int32_t> faces;            // 3 one-based indices per face
+    std::vector<ObjObject> objects;
+};
+
+bool scan_obj(const char* text, size_t len, ObjFile& f) {
+    Scanner sc(text, len);
+    if (sc.literal("mtllib")) { sq_set_error("obj: expected 'mtllib' at byte %zu", sc.i); return false; }   // src/Obj.hs:126-127
+    sc.skip_ws();
+    if (!sc.word(f.mtllib)) return false;
+    while (sc.peek() == 'o') {                                                                              // many parseObj, src/Obj.hs:97-103
+        ++sc.i; sc.skip_ws();
+        size_t name_len = 0;
+        while (Scanner::alnum(sc.peek()) || sc.peek() == '.' || sc.peek() == '_') { ++sc.i; ++name_len; }  // src/Obj.hs:105-107
+        if (!name_len) { sq_set_error("obj: empty object name at byte %zu", sc.i); return false; }
+        sc.skip_ws();
+        while (sc.peek() == 'v') {                                                                          // src/Obj.hs:109-110
+            ++sc.i; sc.skip_ws();
+            float v[3];
+            if (!sc.vec3(v)) return false;
+            f.verts.push_back(sq::mk(v[0], v[2], v[1]));                                                    // swapYZ, src/Obj.hs:112-113
+        }
+        if (sc.literal("usemtl")) { sq_set_error("obj: expected 'usemtl' at byte %zu", sc.i); return false; } // src/Obj.hs:123-124
+        sc.skip_ws();
+        ObjObject ob;
+        if (!sc.word(ob.mtl)) return false;
+        if (sc.peek() == 's') {                                                                             // optional parseS, src/Obj.hs:132-133
+            size_t mark = sc.i;
+            if (sc.literal("s on")) {
+                sc.i = mark;
+                if (sc.literal("s off")) { sq_set_error("obj: bad 's' line at byte %zu", sc.i); return false; }
+            }
+            sc.skip_ws();
+        }
+        ob.face_begin = f.faces.size() / 3;
+        while (sc.peek() == 'f') {                                                                          // src/Obj.hs:135-144
+            ++sc.i; sc.skip_ws();
+            for (int k = 0; k < 3; ++k) {
+                if (!Scanner::digit(sc.peek())) { sq_set_error("obj: expected a face index at byte %zu", sc.i); return false; }
+                long long v = 0;
+                while (Scanner::digit(sc.peek())) { v = v * 10 + (sc.peek() - '0'); if (v > 2000000000LL) v = 2000000000LL; ++sc.i; }
+                sc.skip_ws();
+                f.faces.push_back((int32_t)v);
+            }
+        }
+        ob.face_end = f.faces.size() / 3;
+        f.objects.push_back(ob);
+    }
+    return true;
+}
+
+bool scan_sq(const char* text, size_t len, std::vector<std::string>& names, std::vector<sq_material>& mats) {  // src/Obj.hs:146-161
+    Scanner sc(text, len);
+    for (;;) {
+        int r = sc.literal("newmtl ");
+        if (r == 1) break;
+        if (r == 2) { sq_set_error("sq: expected 'newmtl ' at byte %zu", sc.i); return false; }
+        std::string name; sq_material m;
+        if (!sc.word(name)) return false;
+        sc.skip_ws();
+        if (sc.literal("reflective ")) { sq_set_error("sq: expected 'reflective ' at byte %zu", sc.i); return false; }
+        if (!sc.number(m.reflective)) return false;
+        sc.skip_ws();
+        if (!sc.vec3(m.surf)) return false;
+        sc.skip_ws();
+        if (sc.literal("emissive ")) { sq_set_error("sq: expected 'emissive ' at byte %zu", sc.i); return false; }
+        if (!sc.number(m.emissive)) return false;
+        sc.skip_ws();
+        if (!sc.vec3(m.emit)) return false;
+        sc.skip_ws();
+        names.push_back(name); mats.push_back(m);
+    }
+    return true;
+}
+
+bool read_file(const char* path, std::string& out) {
+    FILE* fp = std::fopen(path, "rb");
+    if (!fp) { sq_set_error("cannot open '%s'", path); return false; }
+    char buf[1 << 16]; size_t got;
+    out.clear();
+    while ((got = std::fread(buf, 1, sizeof buf, fp)) > 0) out.append(buf, got);
+    std::fclose(fp);
+    return true;
+}
+
+}  // namespace
+
+extern "C" int sq_mesh_from_text(const char* obj_text, size_t obj_len, const char* sq_text, size_t sq_len, sq_mesh** out) {
+    if (!obj_text || !sq_text || !out) return sq_set_error("null argument");
+    ObjFile f; std::vector<std::string> names; std::vector<sq_material> mats;
+    if (!scan_obj(obj_text, obj_len, f)) return 1;
+    if (!scan_sq(sq_text, sq_len, names, mats)) return 1;
+    sq_mesh* m = new sq_mesh;
+    m->mats = mats;
+    // makeScene (src/Obj.hs:73-77): every (object, material) pair with equal names, objects outermost.
+    for (const ObjObject& ob : f.objects)
+        for (size_t mi = 0; mi < names.size(); ++mi) {
+            if (ob.mtl != names[mi]) continue;
+            for (size_t fi = ob.face_begin; fi < ob.face_end; ++fi) {                    // makeTris, src/Obj.hs:80-86
+                sq_tri t;
+                float* dst[3] = { t.v0, t.v1, t.v2 };
+                for (int k = 0; k < 3; ++k) {
+                    int32_t idx = f.faces[3 * fi + k];
+                    if (idx < 1 || (size_t)idx > f.verts.size()) {
+                        delete m;
+                        return sq_set_error("obj: face index %d outside 1..%zu", idx, f.verts.size());
+                    }
+                    f3 v = f.verts[(size_t)idx - 1];
+                    dst[k][0] = v.x; dst[k][1] = v.y; dst[k][2] = v.z;
+                }
+                t.mat = (int32_t)mi;
+                m->tris.push_back(t);
+            }
+        }
+    *out = m;
+    return 0;
+}
+
+extern "C" int sq_mesh_from_obj(const char* obj_path, const char* mtl_dir, sq_mesh** out) {
+    if (!obj_path || !mtl_dir || !out) return sq_set_error("null argument");
+    std::string obj, sqt;
+    if (!read_file(obj_path, obj)) return 1;
+    ObjFile probe;
+    {   // only the first line is needed to find the material file (src/Obj.hs:51-52)
+        Scanner sc(obj.data(), obj.size());
+        if (sc.literal("mtllib")) return sq_set_error("obj: expected 'mtllib' at byte %zu", sc.i);
+        sc.skip_ws();
+        if (!sc.word(probe.mtllib)) return 1;
+    }
+    std::string path = std::string(mtl_dir) + "/" + probe.mtllib;
+    if (!read_file(path.c_str(), sqt)) return 1;
+    return sq_mesh_from_text(obj.data(), obj.size(), sqt.data(), sqt.size(), out);
+}
+
+extern "C" int sq_mesh_from_arrays(const sq_tri* tris, int32_t n_tris, const sq_material* mats, int32_t n_mats, sq_mesh** out) {
+    if ((!tris && n_tris) || (!mats && n_mats) || !out || n_tris < 0 || n_mats < 0) return sq_set_error("bad argument");
+    for (int32_t i = 0; i < n_tris; ++i)
+        if (tris[i].mat < 0 || tris[i].mat >= n_mats) return sq_set_error("triangle %d has material %d outside 0..%d", i, tris[i].mat, n_mats - 1);
+    sq_mesh* m = new sq_mesh;
+    m->tris.assign(tris, tris + n_tris);
+    m->mats.assign(mats, mats + n_mats);
+    *out = m;
+    return 0;
+}
+extern "C" int32_t sq_mesh_num_tris(const sq_mesh* m) { return (int32_t)m->tris.size(); }
+extern "C" int32_t sq_mesh_num_materials(const sq_mesh* m) { return (int32_t)m->mats.size(); }
+extern "C" const sq_tri* sq_mesh_tris(const sq_mesh* m) { return m->tris.data(); }
+extern "C" const sq_material* sq_mesh_materials(const sq_mesh* m) { return m->mats.data(); }
+extern "C" void sq_mesh_free(sq_mesh* m) { delete m; }
+
+// ----------------------------------------------------------------------------------------------
+// Camera (src/Obj.hs:60-70, src/Geometry.hs:90-107)
+// ----------------------------------------------------------------------------------------------
+namespace {
+// Data.Matrix product: every entry is a dot product folded from a zero accumulator, r <- a*b + r.
+void mul3(const float a[9], const float b[9], float o[9]) {
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            float r = 0.0f;
+            for (int k = 0; k < 3; ++k) r = a[3 * i + k] * b[3 * k + j] + r;
+            o[3 * i + j] = r;
+        }
+}
+}  // namespace
+
+extern "C" void sq_rot_matrix_rads(float alp, float bet, float gam, float out9[9]) {
+    float sa, ca, sb, cb, sg, cg;
+    sq::fsincos(alp, sa, ca); sq::fsincos(bet, sb, cb); sq::fsincos(gam, sg, cg);
+    const float rz[9] = { ca, -sa, 0, sa, ca, 0, 0, 0, 1 };
+    const float ry[9] = { cb, 0, sb, 0, 1, 0, -sb, 0, cb };
+    const float rx[9] = { 1, 0, 0, 0, cg, -sg, 0, sg, cg };
+    float yx[9];
+    mul3(ry, rx, yx);            // foldr1 (*): rz * (ry * rx)
+    mul3(rz, yx, out9);
+}
+extern "C" int sq_camera_from_text(const char* text, size_t len, sq_camera* cam) {
+    if (!text || !cam) return sq_set_error("null argument");
+    Scanner sc(text, len);
+    float p[3], e[3];
+    if (!sc.vec3(p) || !sc.vec3(e)) return 1;
+    std::memcpy(cam->pos, p, sizeof p);
+    sq_rot_matrix_rads(e[0], e[1], e[2], cam->rot);
+    return 0;
+}
+extern "C" int sq_camera_from_file(const char* path, sq_camera* cam) {
+    std::string t;
+    if (!path || !read_file(path, t)) return path ? 1 : sq_set_error("null argument");
+    return sq_camera_from_text(t.data(), t.size(), cam);
+}
+
+// ----------------------------------------------------------------------------------------------
+// BIH build (src/BIH.hs:62-99) straight into pre-order arrays.
+// ----------------------------------------------------------------------------------------------
+struct sq_bih {
+    sq_bounds root;
+    std::vector<sq_node> nodes;
+    std::vector<sq_tri> tris;          // leaf order
+    std::vector<sq_material> mats;
+    int32_t height = 0, leaves = 0, longest = 0;
+};
+
+namespace {
+
+struct Builder {
+    const std::vector<sq_tri>& src;
+    sq_bih& out;
+    std::vector<int32_t> scratch;
+
+    static const float* vert(const sq_tri& t, int k) { return k == 0 ? t.v0 : (k == 1 ? t.v1 : t.v2); }
+
+    // boundingBox = getBounds . concatMap vertices (src/Geometry.hs:155-163,195-197): foldl1 min / max
+    sq_bounds bounds_of(const int32_t* ids, size_t n) const {
+        sq_bounds b; bool first = true;
+        for (size_t i = 0; i < n; ++i)
+            for (int k = 0; k < 3; ++k) {
+                const float* v = vert(src[(size_t)ids[i]], k);
+                if (first) { for (int c = 0; c < 3; ++c) b.lo[c] = b.hi[c] = v[c]; first = false; }
+                else for (int c = 0; c < 3; ++c) { b.lo[c] = sq::hmin(b.lo[c], v[c]); b.hi[c] = sq::hmax(b.hi[c], v[c]); }
+            }
+        if (first) for (int c = 0; c < 3; ++c) b.lo[c] = b.hi[c] = 0.0f;
+        return b;
+    }
+    // longestAxis (src/Geometry.hs:190-193): maximumBy keeps the later of equal maxima
+    static int longest_axis(const sq_bounds& b) {
+        int best = 0;
+        for (int c = 1; c < 3; ++c) {
+            float cur = b.hi[best] - b.lo[best], cand = b.hi[c] - b.lo[c];
+            if (!sq::cmp_gt(cur, cand)) best = c;
+        }
+        return best;
+    }
+    // averagePoints (vertices tri), one component (src/Geometry.hs:181-182)
+    float centroid(const sq_tri& t, int ax) const { return (((0.0f + t.v0[ax]) + t.v1[ax]) + t.v2[ax]) / 3.0f; }
+
+    int32_t emit_leaf(const int32_t* ids, size_t n, int depth) {
+        sq_node nd; nd.kind = 3 | ((int32_t)n << 2); nd.lmax = 0; nd.rmin = 0; nd.link = (int32_t)out.tris.size();
+        for (size_t i = 0; i < n; ++i) out.tris.push_back(src[(size_t)ids[i]]);
+        out.nodes.push_back(nd);
+        out.leaves++;
+        if ((int32_t)n > out.longest) out.longest = (int32_t)n;
+        if (depth > out.height) out.height = depth;
+        return (int32_t)out.nodes.size() - 1;
+    }
+
+    // bih bbox geom (src/BIH.hs:67-80); ids[0..n) is reordered in place (stable partition)
+    void build(const sq_bounds& bbox, int32_t* ids, size_t n, int depth) {
+        if (n < 15) { emit_leaf(ids, n, depth); return; }
+        // split (src/BIH.hs:82-99)
+        const int ax = longest_axis(bbox);
+        std::vector<float> cen(n);
+        float sum = 0.0f, count = 0.0f;
+        for (size_t i = 0; i < n; ++i) { cen[i] = centroid(src[(size_t)ids[i]], ax); sum = sum + cen[i]; count = count + 1.0f; }
+        const float plane = sum / count;
+        scratch.resize(n);
+        size_t nl = 0, nr = 0;
+        for (size_t i = 0; i < n; ++i) { if (cen[i] < plane) ids[nl++] = ids[i]; else scratch[nr++] = ids[i]; }
+        for (size_t i = 0; i < nr; ++i) ids[nl + i] = scratch[i];
+        float lm = bbox.lo[ax], rm = bbox.hi[ax];                     // maximumDef / minimumDef defaults
+        for (size_t i = 0; i < nl; ++i) for (int k = 0; k < 3; ++k) {
+            float c = vert(src[(size_t)ids[i]], k)[ax];
+            lm = (i == 0 && k == 0) ? c : sq::hmax(lm, c);
+        }
+        for (size_t i = 0; i < nr; ++i) for (int k = 0; k < 3; ++k) {
+            float c = vert(src[(size_t)ids[nl + i]], k)[ax];
+            rm = (i == 0 && k == 0) ? c : sq::hmin(rm, c);
+        }
+        sq_node nd; nd.kind = ax; nd.lmax = 0.001f + lm; nd.rmin = (-0.001f) + rm; nd.link = -1;
+        const size_t me = out.nodes.size();
+        out.nodes.push_back(nd);
+        if (nl == 0) {                                                // src/BIH.hs:70-72
+            emit_leaf(ids, 0, depth + 1);
+            out.nodes[me].link = emit_leaf(ids, nr, depth + 1);
+        } else if (nr == 0) {                                         // src/BIH.hs:73-75
+            emit_leaf(ids, nl, depth + 1);
+            out.nodes[me].link = emit_leaf(ids, 0, depth + 1);
+        } else {                                                      // src/BIH.hs:76-78
+            sq_bounds lb = bounds_of(ids, nl), rb = bounds_of(ids + nl, nr);
+            build(lb, ids, nl, depth + 1);
+            out.nodes[me].link = (int32_t)out.nodes.size();
+            build(rb, ids + nl, nr, depth + 1);
+        }
+    }
+};
+
+}  // namespace
+
+extern "C" int sq_bih_build(const sq_mesh* mesh, sq_bih** outp) {
+    if (!mesh || !outp) return sq_set_error("null argument");
+    sq_bih* b = new sq_bih;
+    b->mats = mesh->mats;
+    const size_t n = mesh->tris.size();
+    std::vector<int32_t> ids(n);
+    for (size_t i = 0; i < n; ++i) ids[i] = (int32_t)i;
+    Builder bl{ mesh->tris, *b, {} };
+    b->tris.reserve(n);
+    b->root = bl.bounds_of(ids.data(), n);                            // makeBIH, src/BIH.hs:62-65
+    bl.build(b->root, ids.data(), n, 1);
+    *outp = b;
+    return 0;
+}
+extern "C" void sq_bih_scene(const sq_bih* b, sq_scene* out) {
+    out->root = b->root;
+    out->nodes = b->nodes.data(); out->n_nodes = (int32_t)b->nodes.size();
+    out->tris = b->tris.data();   out->n_tris = (int32_t)b->tris.size();
+    out->mats = b->mats.data();   out->n_mats = (int32_t)b->mats.size();
+    out->height = b->height;
+}
+extern "C" int32_t sq_bih_height(const sq_bih* b) { return b->height; }
+extern "C" int32_t sq_bih_num_leaves(const sq_bih* b) { return b->leaves; }
+extern "C" int32_t sq_bih_longest_leaf(const sq_bih* b) { return b->longest; }
+extern "C" void sq_bih_free(sq_bih* b) { delete b; }
