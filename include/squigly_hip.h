@@ -83,6 +83,17 @@ void sq_kernel_timing_reset(sq_device_scene* s);
 /* Tunables (0 = library default). variant selects a kernel implementation; all produce identical bits. */
 int  sq_set_option(sq_device_scene* s, const char* key, int64_t value);
 
+/* Diagnostics for the numeric spec (tests only): evaluate one primitive on the device for n inputs.
+ *   SQ_OP_SQRT/SIN/COS/ACOS/ATAN : a = n floats -> out = n floats        (b unused)
+ *   SQ_OP_DIV                    : a, b = n floats -> out = a/b
+ *   SQ_OP_UNIT_FLOAT             : a = n uint32 -> out = n floats (randomR (0,1), src/Lib.hs:183-188)
+ *   SQ_OP_TFGEN3                 : a = n int64 seeds -> out = 3n uint32 (first three outputs of mkTFGen seed)
+ *   SQ_OP_TONEMAP                : a = 3n floats -> out = 3n bytes (src/Lib.hs:93-104)
+ * a, b, out are HOST pointers. */
+enum { SQ_OP_SQRT = 0, SQ_OP_DIV = 1, SQ_OP_SIN = 2, SQ_OP_COS = 3, SQ_OP_ACOS = 4, SQ_OP_ATAN = 5,
+       SQ_OP_UNIT_FLOAT = 6, SQ_OP_TFGEN3 = 7, SQ_OP_TONEMAP = 8 };
+int sq_debug_eval(int32_t device, int32_t op, const void* a, const void* b, int64_t n, void* out);
+
 int32_t     sq_device_count(void);
 int32_t     sq_abi_version(void);
 const char* sq_last_error(void);

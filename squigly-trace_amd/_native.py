@@ -70,6 +70,7 @@ def lib():
     L.sq_kernel_timing_reset.argtypes = [vp]
     L.sq_kernel_timing_reset.restype = None
     L.sq_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
+    L.sq_debug_eval.argtypes = [i32, i32, vp, vp, C.c_int64, vp]
     # host side
     L.sq_mesh_from_obj.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(vp)]
     L.sq_mesh_from_text.argtypes = [C.c_char_p, sz, C.c_char_p, sz, C.POINTER(vp)]
@@ -98,6 +99,26 @@ def lib():
     return L
 
 
+OPS = {"sqrt": 0, "div": 1, "sin": 2, "cos": 3, "acos": 4, "atan": 5, "unit_float": 6, "tfgen3": 7, "tonemap": 8}
+
+
+def debug_eval(op, a, b=None, device=0):
+    """sq_debug_eval: one primitive of the numeric spec evaluated on the GPU (diagnostics)."""
+    code = OPS[op]
+    if op == "tfgen3":
+        a = np.ascontiguousarray(a, np.int64); n = a.size; out = np.empty((n, 3), np.uint32)
+    elif op == "tonemap":
+        a = np.ascontiguousarray(a, np.float32).reshape(-1, 3); n = len(a); out = np.empty((n, 3), np.uint8)
+    elif op == "unit_float":
+        a = np.ascontiguousarray(a, np.uint32); n = a.size; out = np.empty(n, np.float32)
+    else:
+        a = np.ascontiguousarray(a, np.float32); n = a.size; out = np.empty(n, np.float32)
+    if b is not None:
+        b = np.ascontiguousarray(b, np.float32)
+    check(lib().sq_debug_eval(device, code, a.ctypes.data, b.ctypes.data if b is not None else None, n, out.ctypes.data))
+    return out
+
+
 def check(rc):
     if rc != 0:
         raise SquiglyError(lib().sq_last_error().decode(errors="replace"))
@@ -107,7 +128,7 @@ EXPORTED_SYMBOLS = [
     # include/squigly_hip.h
     "sq_render_rgb8", "sq_render_f32", "sq_scene_upload", "sq_scene_free", "sq_shard_rows",
     "sq_shard_global_row", "sq_render_rows_device", "sq_kernel_timing", "sq_kernel_timing_reset",
-    "sq_set_option", "sq_device_count", "sq_abi_version", "sq_last_error",
+    "sq_set_option", "sq_debug_eval", "sq_device_count", "sq_abi_version", "sq_last_error",
     # include/squigly_host.h
     "sq_mesh_from_obj", "sq_mesh_from_text", "sq_mesh_from_arrays", "sq_mesh_num_tris",
     "sq_mesh_num_materials", "sq_mesh_tris", "sq_mesh_materials", "sq_mesh_free", "sq_camera_from_file",

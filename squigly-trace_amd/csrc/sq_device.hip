@@ -564,6 +564,53 @@ extern "C" int sq_render_f32(const sq_scene* scene, const sq_camera* cam, int32_
     return render_oneshot(scene, cam, samples, w, h, cast, out_avg, nullptr);
 }
 
+// ---- diagnostics: primitives of the numeric spec evaluated on the device ----
+__global__ void sq_debug_kernel(int op, const void* a, const void* b, long long n, void* out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* fa = (const float*)a; const float* fb = (const float*)b; float* fo = (float*)out;
+    switch (op) {
+        case SQ_OP_SQRT: fo[i] = sq::fsqrt(fa[i]); break;
+        case SQ_OP_DIV: fo[i] = fa[i] / fb[i]; break;
+        case SQ_OP_SIN: fo[i] = sq::fsin(fa[i]); break;
+        case SQ_OP_COS: fo[i] = sq::fcos(fa[i]); break;
+        case SQ_OP_ACOS: fo[i] = sq::facos(fa[i]); break;
+        case SQ_OP_ATAN: fo[i] = sq::fatan(fa[i]); break;
+        case SQ_OP_UNIT_FLOAT: fo[i] = sq::unit_float(((const uint32_t*)a)[i]); break;
+        case SQ_OP_TFGEN3: {
+            uint32_t n0, n1, n2; sq::tfgen3(((const long long*)a)[i], n0, n1, n2);
+            uint32_t* o = (uint32_t*)out + 3 * i; o[0] = n0; o[1] = n1; o[2] = n2; break;
+        }
+        case SQ_OP_TONEMAP: tonemap(sq::mk(fa[3 * i], fa[3 * i + 1], fa[3 * i + 2]), (uint8_t*)out + 3 * i); break;
+        default: break;
+    }
+}
+extern "C" int sq_debug_eval(int32_t device, int32_t op, const void* a, const void* b, int64_t n, void* out) {
+    if (!a || !out || n < 0 || op < 0 || op > SQ_OP_TONEMAP) return sq_set_error("bad argument");
+    if (op == SQ_OP_DIV && !b) return sq_set_error("SQ_OP_DIV needs b");
+    if (n == 0) return 0;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return sq_set_error("no such HIP device %d", device);
+    SQ_HIP(hipSetDevice(device));
+    const size_t in_sz = (size_t)n * (op == SQ_OP_TFGEN3 ? 8 : op == SQ_OP_TONEMAP ? 12 : 4);
+    const size_t out_sz = (size_t)n * (op == SQ_OP_TFGEN3 ? 12 : op == SQ_OP_TONEMAP ? 3 : 4);
+    void *da = nullptr, *db = nullptr, *dout = nullptr;
+    int rc = 0;
+    auto body = [&]() -> int {
+        SQ_HIP(hipMalloc(&da, in_sz)); SQ_HIP(hipMalloc(&dout, out_sz));
+        SQ_HIP(hipMemcpy(da, a, in_sz, hipMemcpyHostToDevice));
+        if (op == SQ_OP_DIV) { SQ_HIP(hipMalloc(&db, in_sz)); SQ_HIP(hipMemcpy(db, b, in_sz, hipMemcpyHostToDevice)); }
+        hipLaunchKernelGGL(sq_debug_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, op, da, db, (long long)n, dout);
+        SQ_HIP(hipGetLastError());
+        SQ_HIP(hipDeviceSynchronize());
+        SQ_HIP(hipMemcpy(out, dout, out_sz, hipMemcpyDeviceToHost));
+        return 0;
+    };
+    rc = body();
+    (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout);
+    return rc;
+}
+
 extern "C" int32_t sq_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;

@@ -30,13 +30,9 @@ SQ_HD f3 cross(f3 p, f3 q) {                                                    
     return mk(p.y * q.z - p.z * q.y, p.z * q.x - p.x * q.z, p.x * q.y - p.y * q.x);
 }
 SQ_HD float dot(f3 p, f3 q) { return (p.x * q.x + p.y * q.y) + p.z * q.z; }               // src/V3.hs:25-26
-SQ_HD float fsqrt(float x) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __fsqrt_rn(x);
-#else
-    return __builtin_sqrtf(x);
-#endif
-}
+// IEEE square root on both sides.  (HIP's __fsqrt_rn is the *native* 1-ulp v_sqrt_f32; the builtin
+// lowers to llvm.sqrt, which -fhip-fp32-correctly-rounded-divide-sqrt expands to a correctly rounded one.)
+SQ_HD float fsqrt(float x) { return __builtin_sqrtf(x); }
 SQ_HD float norm(f3 v) { return fsqrt(dot(v, v)); }                                       // src/V3.hs:28-32
 SQ_HD f3 normalize(f3 v) { float n = norm(v); return mk(v.x / n, v.y / n, v.z / n); }     // src/V3.hs:34-37
 SQ_HD float axis_of(f3 v, int ax) { return ax == 0 ? v.x : (ax == 1 ? v.y : v.z); }       // projectToAxis, src/Geometry.hs:200-205
@@ -100,13 +96,7 @@ SQ_HD double asin_tail(double z) {   // sum_{k=1..24} C(2k,k)/(4^k(2k+1)) z^k
     p = p * z + 0x1.3333333333333p-4;  p = p * z + 0x1.5555555555555p-3;
     return p * z;
 }
-SQ_HD double dsqrt(double x) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __dsqrt_rn(x);
-#else
-    return __builtin_sqrt(x);
-#endif
-}
+SQ_HD double dsqrt(double x) { return __builtin_sqrt(x); }
 SQ_HD double acos_(double x) {
     double ax = __builtin_fabs(x);
     if (ax <= 0.5) { double z = x * x; return 0x1.921fb54442d18p+0 - (x + x * asin_tail(z)); }

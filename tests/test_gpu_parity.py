@@ -186,3 +186,36 @@ def test_full_size_properties_c2(sqt, product_scene, oracle_scene, dev):
         assert np.all(gm[y, 0:h:7][miss[y, 0:h:7]])
     stats = json.load(open(os.path.join(GOLDEN, "scene_stats.json")))
     assert stats["height"] == 13
+
+
+def test_device_primitives_bit_exact(sqt, O):
+    """Every primitive of the numeric spec, evaluated on the GPU, equals the oracle bit for bit:
+    IEEE sqrt and divide (no 1-ulp native forms), the crd transcendentals, randomR, TFGen, tonemap."""
+    rng = np.random.default_rng(11)
+    L = O.lib()
+    n = 200000
+    x = np.concatenate([rng.uniform(0, 50, n), 10.0 ** rng.uniform(-40, 38, n), [0.0, 1e-45, 3e-39, np.inf]]).astype(np.float32)
+    assert np.array_equal(bits(sqt.debug_eval("sqrt", x)), bits(np.sqrt(x)))
+    a = np.concatenate([rng.normal(0, 10, n), 10.0 ** rng.uniform(-30, 30, n), [1, 2, 0, -0.0, 1, np.inf]]).astype(np.float32)
+    b = np.concatenate([rng.normal(0, 3, n), 10.0 ** rng.uniform(-30, 30, n), [0, 3, 0, 5, -0.0, np.inf]]).astype(np.float32)
+    with np.errstate(all="ignore"):
+        want = a / b
+    got = sqt.debug_eval("div", a, b)
+    ok = (bits(got) == bits(want)) | (np.isnan(got) & np.isnan(want))
+    assert ok.all(), int((~ok).sum())
+    for op, fn, lo, hi in (("sin", "sqo_sinf", -8, 8), ("cos", "sqo_cosf", -8, 8), ("acos", "sqo_acosf", -1, 1), ("atan", "sqo_atanf", -150, 150)):
+        xs = np.concatenate([rng.uniform(lo, hi, 60000), [lo, hi, 0.0, 0.5, -0.5]]).astype(np.float32)
+        f = getattr(L, fn)
+        want = np.array([f(float(v), O.TRIG_CRD) for v in xs], np.float32)
+        assert np.array_equal(bits(sqt.debug_eval(op, xs)), bits(want)), op
+    u = np.concatenate([rng.integers(0, 2 ** 32, 100000, dtype=np.uint64), [0, 1, 2 ** 32 - 1, 2 ** 31, 2 ** 24 + 1]]).astype(np.uint32)
+    want = (u.astype(np.float32) / np.float32(4294967296.0)).astype(np.float32)
+    assert np.array_equal(bits(sqt.debug_eval("unit_float", u)), bits(want))
+    seeds = np.concatenate([rng.integers(0, 2 ** 40, 3000), [0, 1, 2, 2 ** 32 + 5, 8493465599, -1, -2 ** 63]]).astype(np.int64)
+    got = sqt.debug_eval("tfgen3", seeds)
+    want = np.array([O.tfgen_words(int(s))[:3] for s in seeds], np.uint32)
+    assert np.array_equal(got, want)
+    c = np.concatenate([rng.uniform(0, 3, (20000, 3)), rng.uniform(0, 120, (2000, 3)), [[0, 0, 0], [100, 100, 100], [0, 0, 1], [np.inf, 1, 1]]]).astype(np.float32)
+    got = sqt.debug_eval("tonemap", c)
+    want = np.array([O.tonemap(tuple(float(v) for v in row)) for row in c], np.uint8)
+    assert np.array_equal(got, want)
