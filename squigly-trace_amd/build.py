@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libsquigly_hip.so")
 SOURCES = ["sq_device.hip", "sq_host.cpp"]
-HEADERS = ["sq_math.h", "sq_error.h", "../../include/squigly_hip.h", "../../include/squigly_host.h"]
+HEADERS = ["sq_math.h", "sq_error.h", "sq_scene.h", "../../include/squigly_hip.h", "../../include/squigly_host.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
          "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math",
          "-Wall", "-Wno-unused-function"]

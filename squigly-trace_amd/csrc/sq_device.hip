@@ -1,20 +1,23 @@
 // sq_device.hip — gfx950 kernels and the render half of the C-ABI (include/squigly_hip.h).
 //
-// What runs on the GPU (all hand-written for CDNA4, wave64):
-//   camera-ray generation            src/Lib.hs:107-114
-//   BIH traversal + Moller-Trumbore  src/BIH.hs:101-141, src/Geometry.hs:117-177
-//   bounce / scatter / mirror, RNG   src/Lib.hs:127-137,155-198 (+ tf-random's Threefish block)
-//   ordered per-pixel accumulation   src/Lib.hs:85-88
-//   atan tonemap                     src/Lib.hs:93-104
+// What runs on the GPU (all hand-written for CDNA4, wave64; per-ray primitives in sq_scene.h):
+//   camera-ray generation            src/Lib.hs:107-114                      sq_primary
+//   RNG + bounce (scatter / mirror)  src/Lib.hs:133-134,155-198              sq_gen_bounce1, sq_shade1
+//   BIH traversal + Moller-Trumbore  src/BIH.hs:101-141, Geometry.hs:117-177 sq_trace_rays (dominant kernel)
+//   emissive shade, radiance fold    src/Lib.hs:135-137                      sq_shade1, sq_shade2
+//   ordered per-pixel accumulation   src/Lib.hs:85-88                        sq_accumulate
+//   atan tonemap                     src/Lib.hs:93-104                       sq_accumulate
 //
-// The traversal is the reference's recursion with its call stack made explicit.  A stack frame
-// is either FAR(branch) — "the far child of this branch is still to be visited" — or
-// COMBINE(hit) — "the near child produced this hit, combine it with the far child's result".
-// The register R plays the role of the value returned by the most recently finished call, so the
-// early exit `isClose` (src/BIH.hs:114,121-123) and the tie-breaks of minimumBy (src/BIH.hs:109,115)
-// see exactly the values the Haskell sees.  No fast-math, no FMA contraction.
+// Pipeline ("wavefront" form of renderPixel):  every sample of a pixel shoots the same primary ray
+// (src/Lib.hs:81-87), so it is traced once per pixel; pixels that hit are compacted; then, per batch
+// of samples, bounce rays are generated into a queue, traced by a persistent kernel whose lanes pull
+// the next ray as soon as theirs finishes, shaded, compacted (wave ballot + prefix) into the second
+// bounce queue, traced again, and folded into per-sample radiances that are summed per pixel in
+// sample order.  Every value is computed by the same fp32 expression tree as the reference.
+// An alternative one-lane-per-pixel kernel (sq_render_pixels) is kept as a cross-check variant.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -22,9 +25,10 @@
 
 #include "../../include/squigly_hip.h"
 #include "sq_error.h"
-#include "sq_math.h"
+#include "sq_scene.h"
 
 using sq::f3;
+using namespace sqd;
 
 #define SQ_HIP(expr)                                                                             \
     do {                                                                                         \
@@ -32,276 +36,337 @@ using sq::f3;
         if (e_ != hipSuccess) return sq_set_error("%s failed: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
+constexpr int kBlock = 256;        // per-pixel / per-sample kernels
+constexpr int kTraceBlock = 512;   // persistent trace kernel: 8 waves share one LDS copy of the nodes
+constexpr int kChunk = 256;        // rays a wave reserves from the queue per atomic
+
 // ----------------------------------------------------------------------------------------------
-// Device-resident scene layout (HBM, read-only during a render)
+// Frame description shared by the kernels
 // ----------------------------------------------------------------------------------------------
-constexpr uint32_t kLeafBit = 0x80000000u;     // child reference: leaf index | kLeafBit, or branch index
-constexpr uint32_t kCombineBit = 0x80000000u;  // stack word: triangle index | kCombineBit (then a second word: t)
-constexpr int kBlock = 256;
-
-struct DevBranch {          // 48 B, three 16-byte quads
-    float lo[3]; float lmax;    // traversal box of THIS branch (root bounds clipped along the path, src/BIH.hs:130-141)
-    float hi[3]; float rmin;
-    int32_t axis; uint32_t left, right; int32_t pad;
-};
-struct DevLeaf { int32_t first, count; };
-struct DevTri {             // 48 B: v0 | e1 = v1 - v0 | e2 = v2 - v0 (same rounding as src/Geometry.hs:130-131)
-    float v0[3]; int32_t mat;
-    float e1[3]; float pad1;
-    float e2[3]; float pad2;
-};
-struct DevMat { float reflective, sr, sg, sb, emissive, er, eg, eb; };   // 32 B
-
-struct SceneView {
-    const float4* branches;   // 3 per branch
-    const int2* leaves;
-    const float4* tris;       // 3 per triangle
-    const float4* mats;       // 2 per material
-    float root_lo[3], root_hi[3];
-    uint32_t root_ref;
-    int32_t n_branches, n_leaves, n_tris, n_mats;
-    int32_t stack_words;      // per-lane LDS stack capacity in 32-bit words
-};
-
-struct RenderParams {
-    SceneView sc;
+struct Frame {
     float cam_pos[3]; float cam_rot[9];
     int32_t samples, w, h, cast;
     int32_t row_block, shard, n_shards, local_rows;
     float* out_avg; uint8_t* out_rgb;
 };
+__device__ __forceinline__ void pixel_coords(const Frame& F, long long pix, int& y, int& x) {
+    const int j = (int)(pix / F.h);
+    x = (int)(pix - (long long)j * F.h);
+    const int blk = j / F.row_block;
+    y = (blk * F.n_shards + F.shard) * F.row_block + (j - blk * F.row_block);
+}
 
 // ----------------------------------------------------------------------------------------------
-// Device code
+// Variant 1: one lane per pixel, everything in one kernel (cross-check variant; also raycast mode)
 // ----------------------------------------------------------------------------------------------
-struct Hit { float t, dist; int32_t tri; };   // tri < 0 : Nothing
-
-// intersectsBB (src/Geometry.hs:166-177) on precomputed df = 1/dir
-__device__ __forceinline__ bool slab(float lx, float ly, float lz, float hx, float hy, float hz, f3 o, f3 df) {
-    float t1 = (lx - o.x) * df.x, t2 = (hx - o.x) * df.x;
-    float t3 = (ly - o.y) * df.y, t4 = (hy - o.y) * df.y;
-    float t5 = (lz - o.z) * df.z, t6 = (hz - o.z) * df.z;
-    float tmin = sq::hmax(sq::hmax(sq::hmin(t1, t2), sq::hmin(t3, t4)), sq::hmin(t5, t6));
-    float tmax = sq::hmin(sq::hmin(sq::hmax(t1, t2), sq::hmax(t3, t4)), sq::hmax(t5, t6));
-    return tmax > 0 && tmin < tmax;
-}
-
-// mollerTrumbore (src/Geometry.hs:117-142) on (v0, e1, e2)
-__device__ __forceinline__ bool moller_trumbore(f3 o, f3 d, f3 v0, f3 e1, f3 e2, float& t_out, float& dist_out) {
-    const float eps = 0.0001f;
-    f3 h = sq::cross(d, e2);
-    float a = sq::dot(e1, h);
-    if (a > -eps && a < eps) return false;
-    float f = 1.0f / a;
-    f3 s = o - v0;
-    float u = f * sq::dot(s, h);
-    if (u < 0 || u > 1) return false;
-    f3 q = sq::cross(s, e1);
-    float v = f * sq::dot(d, q);
-    if (v < 0 || u + v > 1) return false;
-    float t = f * sq::dot(e2, q);
-    if (!(t > eps)) return false;
-    f3 p = o + sq::scale(t, d);
-    t_out = t;
-    dist_out = sq::norm(p - o);
-    return true;
-}
-
-// intersectBIH (src/BIH.hs:101-141).  `stk` points at this lane's word 0; consecutive words of a
-// lane are `stride` words apart (lane-minor layout: conflict-free ds_read_b32/ds_write_b32).
-__device__ __forceinline__ Hit trace(const SceneView& S, f3 o, f3 d, uint32_t* stk, int stride) {
-    Hit R; R.t = 0; R.dist = 0; R.tri = -1;
-    const f3 df = sq::mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    uint32_t cur = S.root_ref;
-    int sp = 0;
-    enum { DESCEND = 0, LEAF = 1, UNWIND = 2, DONE = 3 };
-    int mode = (cur & kLeafBit) ? LEAF : DESCEND;
-    if (mode == DESCEND &&
-        !slab(S.root_lo[0], S.root_lo[1], S.root_lo[2], S.root_hi[0], S.root_hi[1], S.root_hi[2], o, df))
-        mode = DONE;                                                    // src/BIH.hs:112 at the root
-    while (mode != DONE) {
-        while (mode == DESCEND) {                                       // Branch equation, src/BIH.hs:111-141
-            const float4 q0 = S.branches[3 * cur], q1 = S.branches[3 * cur + 1], q2 = S.branches[3 * cur + 2];
-            const int ax = __float_as_int(q2.x);
-            const uint32_t left = __float_as_uint(q2.y), right = __float_as_uint(q2.z);
-            const float lmax = q0.w, rmin = q1.w;
-            // left = bbox with hi[ax] := lmax ; right = bbox with lo[ax] := rmin   (src/BIH.hs:130-141)
-            const bool iL = slab(q0.x, q0.y, q0.z, ax == 0 ? lmax : q1.x, ax == 1 ? lmax : q1.y, ax == 2 ? lmax : q1.z, o, df);
-            const bool iR = slab(ax == 0 ? rmin : q0.x, ax == 1 ? rmin : q0.y, ax == 2 ? rmin : q0.z, q1.x, q1.y, q1.z, o, df);
-            if (iL && iR) {
-                const bool l2r = sq::axis_of(d, ax) > 0;                // src/BIH.hs:127
-                stk[sp * stride] = cur; ++sp;                           // FAR(cur)
-                cur = l2r ? left : right;
-            } else if (iL) cur = left;
-            else if (iR) cur = right;
-            else { R.tri = -1; mode = UNWIND; break; }                  // src/BIH.hs:119
-            if (cur & kLeafBit) mode = LEAF;
-        }
-        if (mode == LEAF) {                                             // Leaf equation, src/BIH.hs:105-109
-            const int2 lf = S.leaves[cur & ~kLeafBit];
-            R.tri = -1;
-            for (int i = lf.x; i < lf.x + lf.y; ++i) {
-                const float4 a = S.tris[3 * i], b = S.tris[3 * i + 1], c = S.tris[3 * i + 2];
-                float t, dist;
-                if (moller_trumbore(o, d, sq::mk(a.x, a.y, a.z), sq::mk(b.x, b.y, b.z), sq::mk(c.x, c.y, c.z), t, dist)) {
-                    // minimumBy (comparing dist): replace only when compare best new == GT
-                    if (R.tri < 0 || sq::cmp_gt(R.dist, dist)) { R.t = t; R.dist = dist; R.tri = i; }
-                }
-            }
-            mode = UNWIND;
-        }
-        while (mode == UNWIND) {
-            if (sp == 0) { mode = DONE; break; }
-            --sp;
-            const uint32_t e = stk[sp * stride];
-            if (e & kCombineBit) {                                      // minimumByMay over [near, far], src/BIH.hs:115,120
-                --sp;
-                const float nt = __uint_as_float(stk[sp * stride]);
-                const int32_t ntri = (int32_t)(e & ~kCombineBit);
-                const f3 np = o + sq::scale(nt, d);
-                const float ndist = sq::norm(np - o);
-                if (R.tri < 0 || !sq::cmp_gt(ndist, R.dist)) { R.t = nt; R.dist = ndist; R.tri = ntri; }
-            } else {                                                    // back in branch e, near child returned R
-                const float4 q0 = S.branches[3 * e], q1 = S.branches[3 * e + 1], q2 = S.branches[3 * e + 2];
-                const int ax = __float_as_int(q2.x);
-                const bool l2r = sq::axis_of(d, ax) > 0;
-                if (R.tri >= 0) {
-                    const float p = sq::axis_of(o, ax) + R.t * sq::axis_of(d, ax);   // projectToAxis ax (intersectPoint v)
-                    const bool close = l2r ? (p < q1.w) : (p > q0.w);  // src/BIH.hs:121-123
-                    if (close) continue;                                // src/BIH.hs:114: return near
-                    stk[sp * stride] = __float_as_uint(R.t); ++sp;      // COMBINE(R)
-                    stk[sp * stride] = (uint32_t)R.tri | kCombineBit; ++sp;
-                }
-                cur = l2r ? __float_as_uint(q2.z) : __float_as_uint(q2.y);          // far child
-                mode = (cur & kLeafBit) ? LEAF : DESCEND;
-            }
-        }
-    }
-    return R;
-}
-
-struct Surface {            // what shading needs from a hit triangle
-    f3 n;                   // normal = e1 x e2, un-normalised (src/Geometry.hs:79-80)
-    float reflective; f3 surf; f3 emit;   // emit = emissive *^ emitColor (src/Lib.hs:136)
-};
-__device__ __forceinline__ Surface surface_of(const SceneView& S, int tri) {
-    const float4 a = S.tris[3 * tri], b = S.tris[3 * tri + 1], c = S.tris[3 * tri + 2];
-    const int m = __float_as_int(a.w);
-    const float4 m0 = S.mats[2 * m], m1 = S.mats[2 * m + 1];
-    Surface s;
-    s.n = sq::cross(sq::mk(b.x, b.y, b.z), sq::mk(c.x, c.y, c.z));
-    s.reflective = m0.x; s.surf = sq::mk(m0.y, m0.z, m0.w);
-    s.emit = sq::scale(m1.x, sq::mk(m1.y, m1.z, m1.w));
-    return s;
-}
-
-// bounceRay (src/Lib.hs:155-181): x and u are the SAME draw nu; v is the next draw nv.
-__device__ __forceinline__ f3 bounce_dir(f3 d, const Surface& s, uint32_t nu, uint32_t nv) {
-    const float x = sq::unit_float(nu);
-    if (s.reflective < x) {                                             // scatterRay, src/Lib.hs:166-172
-        const float u = x, v = sq::unit_float(nv);
-        const float th = 2 * sq::kPi * u;
-        const float ph = sq::facos(2 * v - 1);
-        float sth, cth, sph, cph;
-        sq::fsincos(th, sth, cth); sq::fsincos(ph, sph, cph);
-        const f3 nd = sq::mk(cth * sph, sth * sph, cph);                // randomVector, src/Lib.hs:192-198
-        const float old_ = sq::hsignum(sq::dot(d, s.n)), new_ = sq::hsignum(sq::dot(nd, s.n));
-        return (old_ == new_) ? -nd : nd;
-    }
-    const f3 dn = sq::normalize(s.n);                                   // reflectRay, src/Lib.hs:176-181
-    return d - sq::scale(2 * sq::dot(dn, d), dn);
-}
-
-// rgbFloatToPixelRGB (src/Lib.hs:93-104).  floor :: Float -> Word8 wraps mod 256 and maps NaN/Inf to 0.
-__device__ __forceinline__ uint8_t to_word8(float f) {
-    if (!(f == f) || f == __builtin_inff() || f == -__builtin_inff()) return 0;
-    const double fl = __builtin_floor((double)f);
-    double md = fl - 256.0 * __builtin_floor(fl / 256.0);
-    return (uint8_t)(int)md;
-}
-__device__ __forceinline__ void tonemap(f3 c, uint8_t* out) {
-    const float mx = sq::hmax(sq::hmax(c.x, c.y), c.z), mn = sq::hmin(sq::hmin(c.x, c.y), c.z);
-    const float lightness = 0.5f * (mx + mn);
-    const float intensity = sq::fatan(lightness) / (sq::kPi / 2);
-    const f3 s = sq::scale(intensity / mx, c);
-    out[0] = to_word8(s.x * 255); out[1] = to_word8(s.y * 255); out[2] = to_word8(s.z * 255);
-}
-
-// makeRay (src/Lib.hs:107-114) + rotVert (src/Geometry.hs:104-107)
-__device__ __forceinline__ f3 primary_dir(const RenderParams& P, int y, int x) {
-    const float ww = (float)P.w, hh = (float)P.h;
-    const float xoffs = ((float)x - (ww / 2)) / ww;
-    const float yoffs = ((hh / 2) - (float)y) / hh;
-    const float v[3] = { 1.0f, xoffs, yoffs };
-    float o[3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) { float r = 0.0f; for (int k = 0; k < 3; ++k) r = v[k] * P.cam_rot[3 * k + j] + r; o[j] = r; }
-    return sq::mk(o[0], o[1], o[2]);
-}
-
-// One lane per pixel.  The primary ray is traced once per pixel: every sample of a pixel shoots the
-// same primary ray (src/Lib.hs:81-87), so its intersection is the same value each time.
-__global__ void __launch_bounds__(kBlock) sq_render_pixels(const RenderParams P) {
-    extern __shared__ uint32_t lds_stack[];
-    const int tid = threadIdx.x;
-    uint32_t* stk = lds_stack + tid;
-    const long long pix = (long long)blockIdx.x * kBlock + tid;
-    const long long total = (long long)P.local_rows * P.h;
-    if (pix >= total) return;
-    const int j = (int)(pix / P.h), x = (int)(pix % P.h);
-    const int blk = j / P.row_block;
-    const int y = (blk * P.n_shards + P.shard) * P.row_block + (j - blk * P.row_block);
-    const SceneView& S = P.sc;
-    const f3 o0 = sq::mk(P.cam_pos[0], P.cam_pos[1], P.cam_pos[2]);
-    const f3 d0 = primary_dir(P, y, x);
-    const int n = P.samples;
+template <typename StackT>
+__global__ void __launch_bounds__(kBlock) sq_render_pixels(const SceneView S, const Frame F) {
+    extern __shared__ float4 lds_raw[];
+    StackT* stk = reinterpret_cast<StackT*>(lds_raw) + threadIdx.x;
+    const long long pix = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (pix >= (long long)F.local_rows * F.h) return;
+    int y, x; pixel_coords(F, pix, y, x);
+    const GlobalNodes N{ S.branches };
+    const f3 o0 = sq::mk(F.cam_pos[0], F.cam_pos[1], F.cam_pos[2]);
+    const f3 d0 = primary_dir(F.cam_rot, F.w, F.h, y, x);
+    const int n = F.samples;
     f3 sum = sq::mk(0, 0, 0);                                           // sum = foldl (+) 0
-    const Hit h0 = trace(S, o0, d0, stk, kBlock);
+    const Hit h0 = trace_one(S, N, o0, d0, stk, kBlock);
     if (h0.tri >= 0) {
         const Surface s0 = surface_of(S, h0.tri);
         const f3 p0 = o0 + sq::scale(h0.t, d0);
-        if (P.cast) {                                                   // raycast, src/Lib.hs:141-151
+        if (F.cast) {                                                   // raycast, src/Lib.hs:141-151
             const f3 light = sq::mk(0, 3, -1);
             const float dl = sq::norm(p0 - light);
-            const Hit sh = trace(S, p0, light - p0, stk, kBlock);
+            const Hit sh = trace_one(S, N, p0, light - p0, stk, kBlock);
             f3 c = sq::mk(0, 0, 0);
-            if (!(sh.tri >= 0 && !(sh.dist > dl))) {
-                const float4 a = S.tris[3 * h0.tri];
-                const float4 m0 = S.mats[2 * __float_as_int(a.w)];
-                c = sq::scale(2 / dl, sq::mk(m0.y, m0.z, m0.w));
-            }
+            if (!(sh.tri >= 0 && !(sh.dist > dl))) c = sq::scale(2 / dl, s0.surf);
             for (int k = 0; k < n; ++k) sum = sum + c;
         } else {
-            const long long rix = (long long)n * ((long long)x + (long long)y * (long long)P.w);   // src/Lib.hs:85
+            const long long rix = (long long)n * ((long long)x + (long long)y * (long long)F.w);   // src/Lib.hs:85
 #pragma unroll 1
             for (int k = 0; k < n; ++k) {                               // raytrace gen scene ray 0, src/Lib.hs:127-137
                 uint32_t n0, n1, n2;
                 sq::tfgen3(rix + k, n0, n1, n2);
                 f3 L1 = sq::mk(0, 0, 0);
                 const f3 d1 = bounce_dir(d0, s0, n0, n1);
-                const Hit h1 = trace(S, p0, d1, stk, kBlock);
+                const Hit h1 = trace_one(S, N, p0, d1, stk, kBlock);
                 if (h1.tri >= 0) {
                     const Surface s1 = surface_of(S, h1.tri);
                     const f3 p1 = p0 + sq::scale(h1.t, d1);
                     const f3 d2 = bounce_dir(d1, s1, n1, n2);
-                    const Hit h2 = trace(S, p1, d2, stk, kBlock);
+                    const Hit h2 = trace_one(S, N, p1, d2, stk, kBlock);
                     f3 L2 = sq::mk(0, 0, 0);
-                    if (h2.tri >= 0) {
-                        const Surface s2 = surface_of(S, h2.tri);
-                        L2 = s2.surf * sq::mk(0, 0, 0) + s2.emit;
-                    }
+                    if (h2.tri >= 0) { const Surface s2 = surface_of(S, h2.tri); L2 = s2.surf * sq::mk(0, 0, 0) + s2.emit; }
                     L1 = s1.surf * L2 + s1.emit;
                 }
-                const f3 L0 = s0.surf * L1 + s0.emit;
-                sum = sum + L0;
+                sum = sum + (s0.surf * L1 + s0.emit);
             }
         }
-    } else {
-        for (int k = 0; k < n; ++k) sum = sum + sq::mk(0, 0, 0);
     }
     const f3 avg = sq::scale(1 / (float)n, sum);                        // src/Lib.hs:88
-    if (P.out_avg) { float* o = P.out_avg + pix * 3; o[0] = avg.x; o[1] = avg.y; o[2] = avg.z; }
-    if (P.out_rgb) tonemap(avg, P.out_rgb + pix * 3);
+    if (F.out_avg) { float* o = F.out_avg + pix * 3; o[0] = avg.x; o[1] = avg.y; o[2] = avg.z; }
+    if (F.out_rgb) tonemap(avg, F.out_rgb + pix * 3);
+}
+
+// ----------------------------------------------------------------------------------------------
+// Variant 2 (default): wavefront pipeline
+// ----------------------------------------------------------------------------------------------
+struct Work {                 // device workspace of one frame (HBM)
+    // per active pixel (a pixel whose primary ray hits), indexed by a in [0, *n_active)
+    int32_t* n_active;        // device counter
+    int32_t* px_pixel;        // local pixel index
+    float*   px_t0;           // primary hit: t
+    int32_t* px_tri0;         // primary hit: triangle
+    float*   px_sum;          // running ordered sum of sample radiances, 3 floats
+    // per sample slot sid = k_local * A + a
+    uint2*   rng12;           // (n1, n2) of the sample's generator
+    float*   rad;             // finished sample radiance, 3 floats
+    // ray queues (two bounce levels): org.xyz + sid, dir.xyz + aux
+    float4 *q_org[2], *q_dir[2];
+    int2*   q_hit[2];         // (t bits, tri) per queue entry
+    int32_t* q_count[2];      // device counters
+    int32_t* q_head[2];       // dequeue cursors of the persistent trace kernel
+    int64_t  slot_capacity;
+};
+
+// Appends `want` lanes of this wave to a queue with one atomic: wave ballot + prefix rank.
+__device__ __forceinline__ int wave_append(int32_t* counter, bool want) {
+    const unsigned long long m = __ballot(want);
+    if (m == 0) return -1;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)m) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(counter, __popcll(m));
+    base = __shfl(base, leader);
+    return want ? base + __popcll(m & ((1ull << lane) - 1ull)) : -1;
+}
+
+// Primary rays: trace once per pixel, compact the pixels that hit.
+template <typename StackT>
+__global__ void __launch_bounds__(kBlock) sq_primary(const SceneView S, const Frame F, const Work W) {
+    extern __shared__ float4 lds_raw[];
+    StackT* stk = reinterpret_cast<StackT*>(lds_raw) + threadIdx.x;
+    const long long pix = (long long)blockIdx.x * kBlock + threadIdx.x;
+    const bool in = pix < (long long)F.local_rows * F.h;
+    Hit h0; h0.tri = -1; h0.t = 0; h0.dist = 0;
+    if (in) {
+        int y, x; pixel_coords(F, pix, y, x);
+        const GlobalNodes N{ S.branches };
+        h0 = trace_one(S, N, sq::mk(F.cam_pos[0], F.cam_pos[1], F.cam_pos[2]), primary_dir(F.cam_rot, F.w, F.h, y, x), stk, kBlock);
+    }
+    const int a = wave_append(W.n_active, in && h0.tri >= 0);
+    if (a >= 0) {
+        W.px_pixel[a] = (int32_t)pix; W.px_t0[a] = h0.t; W.px_tri0[a] = h0.tri;
+        W.px_sum[3 * a] = 0.0f; W.px_sum[3 * a + 1] = 0.0f; W.px_sum[3 * a + 2] = 0.0f;
+    }
+}
+
+struct Pixel0 { f3 p0, d0; Surface s0; int y, x; };
+__device__ __forceinline__ Pixel0 load_pixel0(const SceneView& S, const Frame& F, const Work& W, int a) {
+    Pixel0 P;
+    pixel_coords(F, W.px_pixel[a], P.y, P.x);
+    P.d0 = primary_dir(F.cam_rot, F.w, F.h, P.y, P.x);
+    P.p0 = sq::mk(F.cam_pos[0], F.cam_pos[1], F.cam_pos[2]) + sq::scale(W.px_t0[a], P.d0);   // intersectPoint, src/Geometry.hs:134
+    P.s0 = surface_of(S, W.px_tri0[a]);
+    return P;
+}
+// surfColor == 0 (an emitter such as data/scene.sq:13-15) makes `surfColor * raytrace ...` exactly +0
+// whenever the nested radiance is finite and >= +0, so the nested rays need not be traced.  Only used
+// when every material component is >= +0 (checked at upload), where that premise holds.
+__device__ __forceinline__ bool absorbs(const SceneView& S, const Surface& s) {
+    return S.nonneg_materials && s.surf.x == 0.0f && s.surf.y == 0.0f && s.surf.z == 0.0f;
+}
+
+// Depth-0 bounce of every sample of the batch: RNG, bounceRay, enqueue ray 1 (src/Lib.hs:133-134).
+__global__ void __launch_bounds__(kBlock) sq_gen_bounce1(const SceneView S, const Frame F, const Work W, int k_base, int k_count) {
+    const int A = *W.n_active;
+    const long long total = (long long)A * k_count;
+    const long long stride = (long long)gridDim.x * kBlock;
+    // every lane of a wave runs the same number of iterations so that wave_append sees whole waves
+    const long long iters = (total + stride - 1) / stride;
+    for (long long it = 0; it < iters; ++it) {
+        const long long sid = it * stride + (long long)blockIdx.x * kBlock + threadIdx.x;
+        const bool live = sid < total;
+        bool want = false; f3 d1 = sq::mk(0, 0, 0); Pixel0 P{};
+        if (live) {
+            const int a = (int)(sid % A), k = k_base + (int)(sid / A);
+            P = load_pixel0(S, F, W, a);
+            if (absorbs(S, P.s0)) {
+                const f3 L0 = P.s0.surf * sq::mk(0, 0, 0) + P.s0.emit;
+                W.rad[3 * sid] = L0.x; W.rad[3 * sid + 1] = L0.y; W.rad[3 * sid + 2] = L0.z;
+            } else {
+                const long long rix = (long long)F.samples * ((long long)P.x + (long long)P.y * (long long)F.w);   // src/Lib.hs:85
+                uint32_t n0, n1, n2;
+                sq::tfgen3(rix + k, n0, n1, n2);                        // mkTFGen (rix + k), src/Lib.hs:86
+                W.rng12[sid] = make_uint2(n1, n2);
+                d1 = bounce_dir(P.d0, P.s0, n0, n1);
+                want = true;
+            }
+        }
+        const int q = wave_append(W.q_count[0], want);
+        if (q >= 0) {
+            W.q_org[0][q] = make_float4(P.p0.x, P.p0.y, P.p0.z, __int_as_float((int)sid));
+            W.q_dir[0][q] = make_float4(d1.x, d1.y, d1.z, 0.0f);
+        }
+    }
+}
+
+// After ray 1: a miss finishes the sample; a hit either finishes it (absorbing surface) or enqueues ray 2.
+__global__ void __launch_bounds__(kBlock) sq_shade1(const SceneView S, const Frame F, const Work W) {
+    const int A = *W.n_active;
+    const int total = *W.q_count[0];
+    const long long stride = (long long)gridDim.x * kBlock;
+    const long long iters = (total + stride - 1) / stride;
+    for (long long it = 0; it < iters; ++it) {
+        const long long q = it * stride + (long long)blockIdx.x * kBlock + threadIdx.x;
+        bool want = false; f3 p1 = sq::mk(0, 0, 0), d2 = sq::mk(0, 0, 0); int sid = 0, tri1 = -1;
+        if (q < total) {
+            const float4 org = W.q_org[0][q], dir = W.q_dir[0][q];
+            const int2 hit = W.q_hit[0][q];
+            sid = __float_as_int(org.w); tri1 = hit.y;
+            if (tri1 < 0) {                                             // raytrace ... 1 = black
+                const Surface s0 = surface_of(S, W.px_tri0[sid % A]);
+                const f3 L0 = s0.surf * sq::mk(0, 0, 0) + s0.emit;
+                W.rad[3 * sid] = L0.x; W.rad[3 * sid + 1] = L0.y; W.rad[3 * sid + 2] = L0.z;
+            } else {
+                const Surface s1 = surface_of(S, tri1);
+                if (absorbs(S, s1)) {
+                    const Surface s0 = surface_of(S, W.px_tri0[sid % A]);
+                    const f3 L1 = s1.surf * sq::mk(0, 0, 0) + s1.emit;
+                    const f3 L0 = s0.surf * L1 + s0.emit;
+                    W.rad[3 * sid] = L0.x; W.rad[3 * sid + 1] = L0.y; W.rad[3 * sid + 2] = L0.z;
+                } else {
+                    const f3 d1 = sq::mk(dir.x, dir.y, dir.z);
+                    p1 = sq::mk(org.x, org.y, org.z) + sq::scale(__int_as_float(hit.x), d1);
+                    const uint2 r = W.rng12[sid];
+                    d2 = bounce_dir(d1, s1, r.x, r.y);                  // gen advanced by one: x = u = p(n1), v = p(n2)
+                    want = true;
+                }
+            }
+        }
+        const int q2 = wave_append(W.q_count[1], want);
+        if (q2 >= 0) {
+            W.q_org[1][q2] = make_float4(p1.x, p1.y, p1.z, __int_as_float(sid));
+            W.q_dir[1][q2] = make_float4(d2.x, d2.y, d2.z, __int_as_float(tri1));
+        }
+    }
+}
+
+// After ray 2: L2 = s2*0 + e2 (or black), L1 = s1*L2 + e1, L0 = s0*L1 + e0   (src/Lib.hs:135-137)
+__global__ void __launch_bounds__(kBlock) sq_shade2(const SceneView S, const Frame F, const Work W) {
+    const int A = *W.n_active;
+    const int total = *W.q_count[1];
+    for (long long q = (long long)blockIdx.x * kBlock + threadIdx.x; q < total; q += (long long)gridDim.x * kBlock) {
+        const int sid = __float_as_int(W.q_org[1][q].w), tri1 = __float_as_int(W.q_dir[1][q].w);
+        const int tri2 = W.q_hit[1][q].y;
+        f3 L2 = sq::mk(0, 0, 0);
+        if (tri2 >= 0) { const Surface s2 = surface_of(S, tri2); L2 = s2.surf * sq::mk(0, 0, 0) + s2.emit; }
+        const Surface s1 = surface_of(S, tri1), s0 = surface_of(S, W.px_tri0[sid % A]);
+        const f3 L1 = s1.surf * L2 + s1.emit;
+        const f3 L0 = s0.surf * L1 + s0.emit;
+        W.rad[3 * sid] = L0.x; W.rad[3 * sid + 1] = L0.y; W.rad[3 * sid + 2] = L0.z;
+    }
+}
+
+// sum outcomes, in sample order (src/Lib.hs:88); on the last batch: avg, tonemap, store.
+__global__ void __launch_bounds__(kBlock) sq_accumulate(const Frame F, const Work W, int k_count, int last) {
+    const int A = *W.n_active;
+    for (int a = blockIdx.x * kBlock + threadIdx.x; a < A; a += gridDim.x * kBlock) {
+        f3 sum = sq::mk(W.px_sum[3 * a], W.px_sum[3 * a + 1], W.px_sum[3 * a + 2]);
+        for (int k = 0; k < k_count; ++k) {
+            const long long sid = (long long)k * A + a;
+            sum = sum + sq::mk(W.rad[3 * sid], W.rad[3 * sid + 1], W.rad[3 * sid + 2]);
+        }
+        if (!last) { W.px_sum[3 * a] = sum.x; W.px_sum[3 * a + 1] = sum.y; W.px_sum[3 * a + 2] = sum.z; continue; }
+        const f3 avg = sq::scale(1 / (float)F.samples, sum);
+        const long long pix = W.px_pixel[a];
+        if (F.out_avg) { float* o = F.out_avg + pix * 3; o[0] = avg.x; o[1] = avg.y; o[2] = avg.z; }
+        if (F.out_rgb) tonemap(avg, F.out_rgb + pix * 3);
+    }
+}
+
+// The dominant kernel.  Persistent: each wave reserves chunks of the ray queue with one atomic and
+// each lane starts its next ray as soon as the previous one is finished, so a wave's lanes stay
+// busy although ray lengths differ by 10x.  The first n_lds branches (breadth-first = the top of
+// the tree) are staged in LDS once per workgroup; every lane keeps its frame stack in LDS
+// (lane-minor layout, one word per frame, at most height-1 frames).
+struct TraceArgs {
+    const float4* org; const float4* dir; int2* hits;
+    const int32_t* n_rays; int32_t* head;
+    int32_t n_lds; int32_t stack_cap; int32_t straggler_lanes;
+};
+template <typename StackT>
+__global__ void __launch_bounds__(kTraceBlock) sq_trace_rays(const SceneView S, const TraceArgs A) {
+    extern __shared__ float4 lds_raw[];
+    float4* lnodes = lds_raw;
+    StackT* stk = reinterpret_cast<StackT*>(lds_raw + 3 * (size_t)A.n_lds) + threadIdx.x;
+    for (int i = threadIdx.x; i < 3 * A.n_lds; i += kTraceBlock) lnodes[i] = S.branches[i];   // coalesced 16-B loads
+    __syncthreads();
+    const LdsNodes N{ lnodes, S.branches, (uint32_t)A.n_lds };
+    const int n = *A.n_rays;
+    const int lane = threadIdx.x & 63;
+    int chunk_cur = 0, chunk_end = 0;       // wave-uniform
+    bool exhausted = false;                 // wave-uniform
+    int my_ray = -1;
+    Trav T; T.mode = M_DONE; T.sp = 0; T.cur = 0; T.R.tri = -1; T.R.t = 0; T.R.dist = 0;
+    T.o = T.d = T.df = sq::mk(0, 0, 0);
+    for (;;) {
+        const bool idle = (T.mode == M_DONE);
+        if (idle && my_ray >= 0) { A.hits[my_ray] = make_int2(__float_as_int(T.R.t), T.R.tri); my_ray = -1; }
+        const unsigned long long m = __ballot(idle);
+        if (m) {
+            if (!exhausted && chunk_cur == chunk_end) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(A.head, kChunk);
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (base >= n) exhausted = true;
+                else { chunk_cur = base; chunk_end = min(base + kChunk, n); }
+            }
+            if (!exhausted) {
+                const int rank = __popcll(m & ((1ull << lane) - 1ull));
+                const int avail = chunk_end - chunk_cur;
+                if (idle && rank < avail) {
+                    my_ray = chunk_cur + rank;
+                    const float4 o = A.org[my_ray], d = A.dir[my_ray];
+                    trav_begin<LdsNodes>(T, S, sq::mk(o.x, o.y, o.z), sq::mk(d.x, d.y, d.z));
+                }
+                chunk_cur += min(__popcll(m), avail);
+            } else if (m == ~0ull) break;
+        }
+        // advance until (almost) every lane has a leaf to test or is finished
+        for (;;) {
+            const bool adv = (T.mode == M_DESCEND) || (T.mode == M_UNWIND);
+            const unsigned long long am = __ballot(adv);
+            if (am == 0) break;
+            if (__popcll(am) <= A.straggler_lanes && __ballot(T.mode == M_LEAF) != 0) break;
+            if (T.mode == M_DESCEND) trav_descend(T, N, stk, kTraceBlock);
+            else if (T.mode == M_UNWIND) trav_unwind(T, S, N, stk, kTraceBlock);
+        }
+        if (T.mode == M_LEAF) trav_leaf(T, S);
+    }
+}
+
+// ---- diagnostics: primitives of the numeric spec evaluated on the device ----
+__global__ void sq_debug_kernel(int op, const void* a, const void* b, long long n, void* out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* fa = (const float*)a; const float* fb = (const float*)b; float* fo = (float*)out;
+    switch (op) {
+        case SQ_OP_SQRT: fo[i] = sq::fsqrt(fa[i]); break;
+        case SQ_OP_DIV: fo[i] = fa[i] / fb[i]; break;
+        case SQ_OP_SIN: fo[i] = sq::fsin(fa[i]); break;
+        case SQ_OP_COS: fo[i] = sq::fcos(fa[i]); break;
+        case SQ_OP_ACOS: fo[i] = sq::facos(fa[i]); break;
+        case SQ_OP_ATAN: fo[i] = sq::fatan(fa[i]); break;
+        case SQ_OP_UNIT_FLOAT: fo[i] = sq::unit_float(((const uint32_t*)a)[i]); break;
+        case SQ_OP_TFGEN3: {
+            uint32_t n0, n1, n2; sq::tfgen3(((const long long*)a)[i], n0, n1, n2);
+            uint32_t* o = (uint32_t*)out + 3 * i; o[0] = n0; o[1] = n1; o[2] = n2; break;
+        }
+        case SQ_OP_TONEMAP: tonemap(sq::mk(fa[3 * i], fa[3 * i + 1], fa[3 * i + 2]), (uint8_t*)out + 3 * i); break;
+        default: break;
+    }
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -311,11 +376,15 @@ struct sq_device_scene {
     int device = 0;
     SceneView view{};
     void *d_branches = nullptr, *d_leaves = nullptr, *d_tris = nullptr, *d_mats = nullptr;
-    int height = 0;
+    int height = 0; bool small_index = false; int n_cu = 256;
+    // workspace (grow-only)
+    Work work{}; void* d_work = nullptr; size_t work_bytes = 0; int64_t work_pixels = 0, work_slots = 0;
     // timing of the dominant kernel
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
     double total_ms = 0; int64_t launches = 0;
-    int64_t opt_timing = 1;
+    // options
+    int64_t opt_timing = 1, opt_variant = 2, opt_slots = 48ll << 20, opt_straggler = 12, opt_trace_blocks_per_cu = 0;
+    const char* last_kernel = "sq_trace_rays";
 };
 
 namespace {
@@ -326,37 +395,37 @@ int validate_tree(const sq_scene& sc, int& height, std::vector<int32_t>& depth_o
     const int32_t n = sc.n_nodes;
     if (n < 1) return sq_set_error("scene has no nodes");
     depth_of.assign((size_t)n, 0);
-    struct Frame { int32_t node, stage; };
-    std::vector<Frame> st;
+    struct Fr { int32_t node, stage; };
+    std::vector<Fr> st;
     st.push_back({ 0, 0 });
     int32_t next = 0;      // next unvisited pre-order index
     depth_of[0] = 1;
     height = 0;
     while (!st.empty()) {
-        Frame& f = st.back();
-        const sq_node& nd = sc.nodes[f.node];
+        const int32_t node = st.back().node; const int stage = st.back().stage;
+        const sq_node& nd = sc.nodes[node];
         const int kind = nd.kind & 3;
-        if (f.stage == 0) {
-            if (f.node != next) return sq_set_error("node %d is not in pre-order position (expected %d)", f.node, next);
+        if (stage == 0) {
+            if (node != next) return sq_set_error("node %d is not in pre-order position (expected %d)", node, next);
             ++next;
-            const int dep = depth_of[(size_t)f.node];
+            const int dep = depth_of[(size_t)node];
             if (dep > height) height = dep;
             if (kind == 3) {
                 const int64_t cnt = nd.kind >> 2, first = nd.link;
-                if (cnt < 0 || first < 0 || first + cnt > sc.n_tris) return sq_set_error("leaf %d has triangle range [%lld,+%lld) outside 0..%d", f.node, (long long)first, (long long)cnt, sc.n_tris);
+                if (cnt < 0 || first < 0 || first + cnt > sc.n_tris) return sq_set_error("leaf %d has triangle range [%lld,+%lld) outside 0..%d", node, (long long)first, (long long)cnt, sc.n_tris);
                 st.pop_back();
                 continue;
             }
-            if ((nd.kind >> 2) != 0) return sq_set_error("branch %d has stray bits in kind", f.node);
-            if (f.node + 1 >= n) return sq_set_error("branch %d has no left child", f.node);
-            f.stage = 1;
-            depth_of[(size_t)f.node + 1] = dep + 1;
-            st.push_back({ f.node + 1, 0 });
-        } else if (f.stage == 1) {
-            if (nd.link != next) return sq_set_error("branch %d: right child link %d, expected %d", f.node, nd.link, next);
-            if (nd.link >= n) return sq_set_error("branch %d: right child %d out of range", f.node, nd.link);
-            f.stage = 2;
-            depth_of[(size_t)nd.link] = depth_of[(size_t)f.node] + 1;
+            if ((nd.kind >> 2) != 0) return sq_set_error("branch %d has stray bits in kind", node);
+            if (node + 1 >= n) return sq_set_error("branch %d has no left child", node);
+            st.back().stage = 1;
+            depth_of[(size_t)node + 1] = dep + 1;
+            st.push_back({ node + 1, 0 });
+        } else if (stage == 1) {
+            if (nd.link != next) return sq_set_error("branch %d: right child link %d, expected %d", node, nd.link, next);
+            if (nd.link >= n) return sq_set_error("branch %d: right child %d out of range", node, nd.link);
+            st.back().stage = 2;
+            depth_of[(size_t)nd.link] = depth_of[(size_t)node] + 1;
             st.push_back({ nd.link, 0 });
         } else st.pop_back();
     }
@@ -379,11 +448,19 @@ extern "C" int sq_scene_upload(const sq_scene* sc, int32_t device, sq_device_sce
     if (validate_tree(*sc, height, depth)) return 1;
     if (sc->height && sc->height != height) return sq_set_error("scene.height = %d but the tree has height %d", sc->height, height);
 
-    // Re-pack: branches and leaves get their own dense tables; each branch carries its traversal box.
+    // Re-pack.  Leaves keep pre-order numbering; branches are numbered breadth-first (stable within a
+    // level) so the top of the tree is a prefix of the branch table.  Each branch carries its traversal box.
     const int32_t n = sc->n_nodes;
     std::vector<uint32_t> ref((size_t)n);
     int32_t nb = 0, nl = 0;
-    for (int32_t i = 0; i < n; ++i) ref[(size_t)i] = ((sc->nodes[i].kind & 3) == 3) ? ((uint32_t)nl++ | kLeafBit) : (uint32_t)nb++;
+    {
+        std::vector<std::vector<int32_t>> by_depth((size_t)height + 1);
+        for (int32_t i = 0; i < n; ++i) {
+            if ((sc->nodes[i].kind & 3) == 3) ref[(size_t)i] = (uint32_t)nl++ | kLeafBit;
+            else by_depth[(size_t)depth[(size_t)i]].push_back(i);
+        }
+        for (auto& level : by_depth) for (int32_t i : level) ref[(size_t)i] = (uint32_t)nb++;
+    }
     std::vector<DevBranch> br((size_t)nb);
     std::vector<DevLeaf> lf((size_t)nl);
     std::vector<sq_bounds> box((size_t)n);
@@ -408,13 +485,19 @@ extern "C" int sq_scene_upload(const sq_scene* sc, int32_t device, sq_device_sce
         d.mat = t.mat; d.pad1 = d.pad2 = 0;
     }
     std::vector<DevMat> mt((size_t)sc->n_mats);
+    bool nonneg = true;
     for (int32_t i = 0; i < sc->n_mats; ++i) {
         const sq_material& m = sc->mats[i];
         mt[(size_t)i] = { m.reflective, m.surf[0], m.surf[1], m.surf[2], m.emissive, m.emit[0], m.emit[1], m.emit[2] };
+        const float comp[8] = { m.reflective, m.surf[0], m.surf[1], m.surf[2], m.emissive, m.emit[0], m.emit[1], m.emit[2] };
+        for (float c : comp) { uint32_t bits; std::memcpy(&bits, &c, 4); if ((bits >> 31) || !(c == c) || c > 3.0e38f) nonneg = false; }
     }
     SQ_HIP(hipSetDevice(device));
     sq_device_scene* s = new sq_device_scene;
     s->device = device; s->height = height;
+    s->small_index = nb < 0x8000 && sc->n_tris < 0x8000;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) s->n_cu = prop.multiProcessorCount;
     auto up = [&](void** dst, const void* src, size_t bytes) -> int {
         if (hipMalloc(dst, bytes ? bytes : 16) != hipSuccess) return sq_set_error("hipMalloc(%zu) failed", bytes);
         if (bytes && hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) != hipSuccess) return sq_set_error("hipMemcpy H2D failed");
@@ -431,7 +514,7 @@ extern "C" int sq_scene_upload(const sq_scene* sc, int32_t device, sq_device_sce
     for (int c = 0; c < 3; ++c) { v.root_lo[c] = sc->root.lo[c]; v.root_hi[c] = sc->root.hi[c]; }
     v.root_ref = ref[0];
     v.n_branches = nb; v.n_leaves = nl; v.n_tris = sc->n_tris; v.n_mats = sc->n_mats;
-    v.stack_words = 2 * height + 2;        // one frame per level, a COMBINE frame is two words
+    v.height = height; v.nonneg_materials = nonneg ? 1 : 0;
     *out = s;
     return 0;
 }
@@ -441,6 +524,7 @@ extern "C" void sq_scene_free(sq_device_scene* s) {
     (void)hipSetDevice(s->device);
     for (auto& p : s->pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     (void)hipFree(s->d_branches); (void)hipFree(s->d_leaves); (void)hipFree(s->d_tris); (void)hipFree(s->d_mats);
+    (void)hipFree(s->d_work);
     delete s;
 }
 
@@ -459,6 +543,99 @@ extern "C" int32_t sq_shard_global_row(int32_t j, sq_shard sh) {
     return (blk * sh.n_shards + sh.shard) * sh.row_block + (j - blk * sh.row_block);
 }
 
+namespace {
+
+// Carves the frame workspace out of one allocation (grow-only; allocation happens outside timed steps after warm-up).
+int ensure_workspace(sq_device_scene* s, int64_t pixels, int64_t slots) {
+    if (pixels <= s->work_pixels && slots <= s->work_slots && s->d_work) return 0;
+    pixels = std::max(pixels, s->work_pixels); slots = std::max(slots, s->work_slots);
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += al(bytes); return o; };
+    const size_t o_cnt = take(64 * sizeof(int32_t));
+    const size_t o_pix = take(pixels * 4), o_t0 = take(pixels * 4), o_tri0 = take(pixels * 4), o_sum = take(pixels * 12);
+    const size_t o_rng = take(slots * 8), o_rad = take(slots * 12);
+    size_t o_org[2], o_dir[2], o_hit[2];
+    for (int i = 0; i < 2; ++i) { o_org[i] = take(slots * 16); o_dir[i] = take(slots * 16); o_hit[i] = take(slots * 8); }
+    if (s->d_work) { (void)hipFree(s->d_work); s->d_work = nullptr; }
+    if (hipMalloc(&s->d_work, off) != hipSuccess) return sq_set_error("hipMalloc(%zu B) for the frame workspace failed", off);
+    char* base = (char*)s->d_work;
+    Work& W = s->work;
+    int32_t* cnt = (int32_t*)(base + o_cnt);
+    W.n_active = cnt; W.q_count[0] = cnt + 16; W.q_count[1] = cnt + 17; W.q_head[0] = cnt + 32; W.q_head[1] = cnt + 33;
+    W.px_pixel = (int32_t*)(base + o_pix); W.px_t0 = (float*)(base + o_t0); W.px_tri0 = (int32_t*)(base + o_tri0); W.px_sum = (float*)(base + o_sum);
+    W.rng12 = (uint2*)(base + o_rng); W.rad = (float*)(base + o_rad);
+    for (int i = 0; i < 2; ++i) { W.q_org[i] = (float4*)(base + o_org[i]); W.q_dir[i] = (float4*)(base + o_dir[i]); W.q_hit[i] = (int2*)(base + o_hit[i]); }
+    W.slot_capacity = slots;
+    s->work_bytes = off; s->work_pixels = pixels; s->work_slots = slots;
+    return 0;
+}
+
+template <typename StackT>
+int launch_frame(sq_device_scene* s, const Frame& F, hipStream_t stream) {
+    const SceneView& S = s->view;
+    const long long pixels = (long long)F.local_rows * F.h;
+    const int stack_cap = std::max(S.height, 1);
+    const size_t px_lds = (size_t)kBlock * stack_cap * sizeof(StackT);
+    const long long px_blocks = (pixels + kBlock - 1) / kBlock;
+    if (px_blocks > 0x7fffffffLL) return sq_set_error("image too large for one launch");
+    if (px_lds > 160 * 1024) return sq_set_error("BIH height %d needs %zu B of LDS stack per workgroup (max 163840)", S.height, px_lds);
+    auto timed = [&](auto&& fn, const char* name) -> int {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (s->opt_timing) { SQ_HIP(hipEventCreate(&e0)); SQ_HIP(hipEventCreate(&e1)); SQ_HIP(hipEventRecord(e0, stream)); }
+        fn();
+        SQ_HIP(hipGetLastError());
+        if (s->opt_timing) { SQ_HIP(hipEventRecord(e1, stream)); s->pending.emplace_back(e0, e1); s->last_kernel = name; }
+        return 0;
+    };
+    if (s->opt_variant == 1 || F.cast) {
+        if (px_lds > 64 * 1024) SQ_HIP(hipFuncSetAttribute((const void*)sq_render_pixels<StackT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)px_lds));
+        return timed([&] { hipLaunchKernelGGL(sq_render_pixels<StackT>, dim3((unsigned)px_blocks), dim3(kBlock), px_lds, stream, S, F); }, "sq_render_pixels");
+    }
+    // ---- wavefront pipeline ----
+    const int64_t slots = std::max<int64_t>(s->opt_slots, pixels);          // at least one sample of every pixel per batch
+    if (ensure_workspace(s, pixels, slots)) return 1;
+    const Work& W = s->work;
+    const int batch = (int)std::max<int64_t>(1, std::min<int64_t>(F.samples, slots / pixels));
+    if (F.out_avg) SQ_HIP(hipMemsetAsync(F.out_avg, 0, (size_t)pixels * 3 * sizeof(float), stream));   // pixels whose primary ray misses: black
+    if (F.out_rgb) SQ_HIP(hipMemsetAsync(F.out_rgb, 0, (size_t)pixels * 3, stream));
+    SQ_HIP(hipMemsetAsync(W.n_active, 0, 64 * sizeof(int32_t), stream));
+    if (px_lds > 64 * 1024) SQ_HIP(hipFuncSetAttribute((const void*)sq_primary<StackT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)px_lds));
+    hipLaunchKernelGGL(sq_primary<StackT>, dim3((unsigned)px_blocks), dim3(kBlock), px_lds, stream, S, F, W);
+    SQ_HIP(hipGetLastError());
+    // persistent trace kernel geometry: LDS = staged branches + stacks
+    const size_t stack_bytes = (size_t)kTraceBlock * stack_cap * sizeof(StackT);
+    const size_t lds_budget = 160 * 1024;
+    int n_lds = S.n_branches;
+    const size_t max_node_bytes = 64 * 1024;                               // leave room for >= 2 workgroups per CU
+    if ((size_t)n_lds * 48 > max_node_bytes) n_lds = (int)(max_node_bytes / 48);
+    const size_t tr_lds = (((size_t)n_lds * 48 + 15) & ~(size_t)15) + stack_bytes;
+    if (tr_lds > lds_budget) return sq_set_error("BIH height %d needs %zu B of LDS per workgroup (max %zu)", S.height, tr_lds, lds_budget);
+    if (tr_lds > 64 * 1024) SQ_HIP(hipFuncSetAttribute((const void*)sq_trace_rays<StackT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tr_lds));
+    int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, lds_budget / tr_lds));
+    if (s->opt_trace_blocks_per_cu > 0) per_cu = (int)s->opt_trace_blocks_per_cu;
+    const int trace_blocks = s->n_cu * per_cu;
+    const int aux_blocks = s->n_cu * 8;
+    for (int k0 = 0; k0 < F.samples; k0 += batch) {
+        const int kc = std::min(batch, F.samples - k0);
+        SQ_HIP(hipMemsetAsync(W.q_count[0], 0, 32 * sizeof(int32_t), stream));   // both queue counters and both cursors
+        hipLaunchKernelGGL(sq_gen_bounce1, dim3(aux_blocks), dim3(kBlock), 0, stream, S, F, W, k0, kc);
+        SQ_HIP(hipGetLastError());
+        for (int level = 0; level < 2; ++level) {
+            TraceArgs A{ W.q_org[level], W.q_dir[level], W.q_hit[level], W.q_count[level], W.q_head[level], n_lds, stack_cap, (int32_t)s->opt_straggler };
+            if (timed([&] { hipLaunchKernelGGL(sq_trace_rays<StackT>, dim3(trace_blocks), dim3(kTraceBlock), tr_lds, stream, S, A); }, "sq_trace_rays")) return 1;
+            if (level == 0) hipLaunchKernelGGL(sq_shade1, dim3(aux_blocks), dim3(kBlock), 0, stream, S, F, W);
+            else hipLaunchKernelGGL(sq_shade2, dim3(aux_blocks), dim3(kBlock), 0, stream, S, F, W);
+            SQ_HIP(hipGetLastError());
+        }
+        hipLaunchKernelGGL(sq_accumulate, dim3(aux_blocks), dim3(kBlock), 0, stream, F, W, kc, (k0 + kc >= F.samples) ? 1 : 0);
+        SQ_HIP(hipGetLastError());
+    }
+    return 0;
+}
+
+}  // namespace
+
 extern "C" int sq_render_rows_device(sq_device_scene* s, const sq_camera* cam, int32_t samples, int32_t w, int32_t h,
                                      int32_t cast, sq_shard sh, float* d_avg, uint8_t* d_rgb, void* hip_stream) {
     if (!s || !cam) return sq_set_error("null argument");
@@ -468,33 +645,14 @@ extern "C" int sq_render_rows_device(sq_device_scene* s, const sq_camera* cam, i
     if (!d_avg && !d_rgb) return sq_set_error("no output buffer");
     if (rows == 0) return 0;
     SQ_HIP(hipSetDevice(s->device));
+    Frame F{};
+    std::memcpy(F.cam_pos, cam->pos, sizeof F.cam_pos);
+    std::memcpy(F.cam_rot, cam->rot, sizeof F.cam_rot);
+    F.samples = samples; F.w = w; F.h = h; F.cast = cast ? 1 : 0;
+    F.row_block = sh.row_block; F.shard = sh.shard; F.n_shards = sh.n_shards; F.local_rows = rows;
+    F.out_avg = d_avg; F.out_rgb = d_rgb;
     hipStream_t stream = (hipStream_t)hip_stream;
-    RenderParams P{};
-    P.sc = s->view;
-    std::memcpy(P.cam_pos, cam->pos, sizeof P.cam_pos);
-    std::memcpy(P.cam_rot, cam->rot, sizeof P.cam_rot);
-    P.samples = samples; P.w = w; P.h = h; P.cast = cast ? 1 : 0;
-    P.row_block = sh.row_block; P.shard = sh.shard; P.n_shards = sh.n_shards; P.local_rows = rows;
-    P.out_avg = d_avg; P.out_rgb = d_rgb;
-    const long long total = (long long)rows * h;
-    const long long blocks = (total + kBlock - 1) / kBlock;
-    if (blocks > 0x7fffffffLL) return sq_set_error("image too large for one launch");
-    const size_t lds = (size_t)kBlock * (size_t)s->view.stack_words * sizeof(uint32_t);
-    if (lds > 160 * 1024) return sq_set_error("BIH height %d needs %zu B of LDS stack per workgroup (max 163840)", s->height, lds);
-    if (lds > 64 * 1024)
-        SQ_HIP(hipFuncSetAttribute((const void*)sq_render_pixels, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (s->opt_timing) {
-        SQ_HIP(hipEventCreate(&e0)); SQ_HIP(hipEventCreate(&e1));
-        SQ_HIP(hipEventRecord(e0, stream));
-    }
-    hipLaunchKernelGGL(sq_render_pixels, dim3((unsigned)blocks), dim3(kBlock), lds, stream, P);
-    SQ_HIP(hipGetLastError());
-    if (s->opt_timing) {
-        SQ_HIP(hipEventRecord(e1, stream));
-        s->pending.emplace_back(e0, e1);
-    }
-    return 0;
+    return s->small_index ? launch_frame<uint16_t>(s, F, stream) : launch_frame<uint32_t>(s, F, stream);
 }
 
 extern "C" int sq_kernel_timing(sq_device_scene* s, double* avg_ms, int64_t* launches, const char** name) {
@@ -510,7 +668,7 @@ extern "C" int sq_kernel_timing(sq_device_scene* s, double* avg_ms, int64_t* lau
     s->pending.clear();
     if (avg_ms) *avg_ms = s->launches ? s->total_ms / (double)s->launches : 0.0;
     if (launches) *launches = s->launches;
-    if (name) *name = "sq_render_pixels";
+    if (name) *name = s->last_kernel;
     return 0;
 }
 extern "C" void sq_kernel_timing_reset(sq_device_scene* s) {
@@ -521,6 +679,10 @@ extern "C" void sq_kernel_timing_reset(sq_device_scene* s) {
 extern "C" int sq_set_option(sq_device_scene* s, const char* key, int64_t value) {
     if (!s || !key) return sq_set_error("null argument");
     if (!std::strcmp(key, "timing")) { s->opt_timing = value; return 0; }
+    if (!std::strcmp(key, "variant")) { if (value != 1 && value != 2) return sq_set_error("variant must be 1 (per-pixel kernel) or 2 (wavefront)"); s->opt_variant = value; return 0; }
+    if (!std::strcmp(key, "slots")) { if (value < 1) return sq_set_error("slots must be positive"); s->opt_slots = value; return 0; }
+    if (!std::strcmp(key, "straggler_lanes")) { if (value < 0 || value > 63) return sq_set_error("straggler_lanes must be in 0..63"); s->opt_straggler = value; return 0; }
+    if (!std::strcmp(key, "trace_blocks_per_cu")) { if (value < 0 || value > 8) return sq_set_error("trace_blocks_per_cu must be in 0..8"); s->opt_trace_blocks_per_cu = value; return 0; }
     return sq_set_error("unknown option '%s'", key);
 }
 
@@ -532,6 +694,7 @@ int render_oneshot(const sq_scene* scene, const sq_camera* cam, int32_t samples,
     if (samples < 1 || w < 1 || h < 1) return sq_set_error("samples, width and height must be positive (got %d, %d, %d)", samples, w, h);
     sq_device_scene* s = nullptr;
     if (sq_scene_upload(scene, 0, &s)) return 1;
+    if (const char* v = std::getenv("SQ_VARIANT")) s->opt_variant = (std::atoi(v) == 1) ? 1 : 2;
     const size_t npx = (size_t)w * (size_t)h * 3;
     float* d_avg = nullptr; uint8_t* d_rgb = nullptr;
     std::vector<float> h_avg; std::vector<uint8_t> h_rgb;
@@ -564,27 +727,6 @@ extern "C" int sq_render_f32(const sq_scene* scene, const sq_camera* cam, int32_
     return render_oneshot(scene, cam, samples, w, h, cast, out_avg, nullptr);
 }
 
-// ---- diagnostics: primitives of the numeric spec evaluated on the device ----
-__global__ void sq_debug_kernel(int op, const void* a, const void* b, long long n, void* out) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float* fa = (const float*)a; const float* fb = (const float*)b; float* fo = (float*)out;
-    switch (op) {
-        case SQ_OP_SQRT: fo[i] = sq::fsqrt(fa[i]); break;
-        case SQ_OP_DIV: fo[i] = fa[i] / fb[i]; break;
-        case SQ_OP_SIN: fo[i] = sq::fsin(fa[i]); break;
-        case SQ_OP_COS: fo[i] = sq::fcos(fa[i]); break;
-        case SQ_OP_ACOS: fo[i] = sq::facos(fa[i]); break;
-        case SQ_OP_ATAN: fo[i] = sq::fatan(fa[i]); break;
-        case SQ_OP_UNIT_FLOAT: fo[i] = sq::unit_float(((const uint32_t*)a)[i]); break;
-        case SQ_OP_TFGEN3: {
-            uint32_t n0, n1, n2; sq::tfgen3(((const long long*)a)[i], n0, n1, n2);
-            uint32_t* o = (uint32_t*)out + 3 * i; o[0] = n0; o[1] = n1; o[2] = n2; break;
-        }
-        case SQ_OP_TONEMAP: tonemap(sq::mk(fa[3 * i], fa[3 * i + 1], fa[3 * i + 2]), (uint8_t*)out + 3 * i); break;
-        default: break;
-    }
-}
 extern "C" int sq_debug_eval(int32_t device, int32_t op, const void* a, const void* b, int64_t n, void* out) {
     if (!a || !out || n < 0 || op < 0 || op > SQ_OP_TONEMAP) return sq_set_error("bad argument");
     if (op == SQ_OP_DIV && !b) return sq_set_error("SQ_OP_DIV needs b");
@@ -595,7 +737,6 @@ extern "C" int sq_debug_eval(int32_t device, int32_t op, const void* a, const vo
     const size_t in_sz = (size_t)n * (op == SQ_OP_TFGEN3 ? 8 : op == SQ_OP_TONEMAP ? 12 : 4);
     const size_t out_sz = (size_t)n * (op == SQ_OP_TFGEN3 ? 12 : op == SQ_OP_TONEMAP ? 3 : 4);
     void *da = nullptr, *db = nullptr, *dout = nullptr;
-    int rc = 0;
     auto body = [&]() -> int {
         SQ_HIP(hipMalloc(&da, in_sz)); SQ_HIP(hipMalloc(&dout, out_sz));
         SQ_HIP(hipMemcpy(da, a, in_sz, hipMemcpyHostToDevice));
@@ -606,7 +747,7 @@ extern "C" int sq_debug_eval(int32_t device, int32_t op, const void* a, const vo
         SQ_HIP(hipMemcpy(out, dout, out_sz, hipMemcpyDeviceToHost));
         return 0;
     };
-    rc = body();
+    const int rc = body();
     (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout);
     return rc;
 }

@@ -1,0 +1,252 @@
+// sq_scene.h — device-resident scene layout and the per-ray primitives shared by all kernels.
+// Citations are relative to the reference repository root.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sq_math.h"
+
+namespace sqd {
+using sq::f3;
+
+constexpr uint32_t kLeafBit = 0x80000000u;   // child reference: leaf index | kLeafBit, or branch index
+
+// HBM layout (read-only during a render).  Branches are numbered breadth-first so that the top
+// of the tree is a prefix of the table (that prefix is what gets staged in LDS).
+struct DevBranch {          // 48 B, three 16-byte quads
+    float lo[3]; float lmax;    // traversal box of THIS branch: root bounds clipped along the path (src/BIH.hs:130-141)
+    float hi[3]; float rmin;
+    int32_t axis; uint32_t left, right; int32_t pad;
+};
+struct DevLeaf { int32_t first, count; };
+struct DevTri {             // 48 B: v0 | e1 = v1 - v0 | e2 = v2 - v0 (same rounding as src/Geometry.hs:130-131)
+    float v0[3]; int32_t mat;
+    float e1[3]; float pad1;
+    float e2[3]; float pad2;
+};
+struct DevMat { float reflective, sr, sg, sb, emissive, er, eg, eb; };   // 32 B
+
+struct SceneView {
+    const float4* branches;   // 3 quads per branch
+    const int2* leaves;
+    const float4* tris;       // 3 quads per triangle
+    const float4* mats;       // 2 quads per material
+    float root_lo[3], root_hi[3];
+    uint32_t root_ref;
+    int32_t n_branches, n_leaves, n_tris, n_mats;
+    int32_t height;           // BIH.height; a traversal never holds more than height-1 frames
+    int32_t nonneg_materials; // 1 if every material component is >= +0 (enables the exact s == 0 shortcuts)
+};
+
+struct Hit { float t, dist; int32_t tri; };   // tri < 0 : Nothing
+
+// intersectsBB (src/Geometry.hs:166-177) with df = 1/dir precomputed (the reference recomputes the same value)
+__device__ __forceinline__ bool slab(float lx, float ly, float lz, float hx, float hy, float hz, f3 o, f3 df) {
+    const float t1 = (lx - o.x) * df.x, t2 = (hx - o.x) * df.x;
+    const float t3 = (ly - o.y) * df.y, t4 = (hy - o.y) * df.y;
+    const float t5 = (lz - o.z) * df.z, t6 = (hz - o.z) * df.z;
+    const float tmin = sq::hmax(sq::hmax(sq::hmin(t1, t2), sq::hmin(t3, t4)), sq::hmin(t5, t6));
+    const float tmax = sq::hmin(sq::hmin(sq::hmax(t1, t2), sq::hmax(t3, t4)), sq::hmax(t5, t6));
+    return tmax > 0 && tmin < tmax;
+}
+
+// mollerTrumbore (src/Geometry.hs:117-142) on (v0, e1, e2)
+__device__ __forceinline__ bool moller_trumbore(f3 o, f3 d, f3 v0, f3 e1, f3 e2, float& t_out, float& dist_out) {
+    const float eps = 0.0001f;
+    const f3 h = sq::cross(d, e2);
+    const float a = sq::dot(e1, h);
+    if (a > -eps && a < eps) return false;
+    const float f = 1.0f / a;
+    const f3 s = o - v0;
+    const float u = f * sq::dot(s, h);
+    if (u < 0 || u > 1) return false;
+    const f3 q = sq::cross(s, e1);
+    const float v = f * sq::dot(d, q);
+    if (v < 0 || u + v > 1) return false;
+    const float t = f * sq::dot(e2, q);
+    if (!(t > eps)) return false;
+    const f3 p = o + sq::scale(t, d);
+    t_out = t;
+    dist_out = sq::norm(p - o);
+    return true;
+}
+
+struct Surface {            // what shading needs from a hit triangle
+    f3 n;                   // normal = e1 x e2, un-normalised (src/Geometry.hs:79-80)
+    float reflective; f3 surf; f3 emit;   // emit = emissive *^ emitColor (src/Lib.hs:136)
+};
+__device__ __forceinline__ Surface surface_of(const SceneView& S, int tri) {
+    const float4 a = S.tris[3 * tri], b = S.tris[3 * tri + 1], c = S.tris[3 * tri + 2];
+    const int m = __float_as_int(a.w);
+    const float4 m0 = S.mats[2 * m], m1 = S.mats[2 * m + 1];
+    Surface s;
+    s.n = sq::cross(sq::mk(b.x, b.y, b.z), sq::mk(c.x, c.y, c.z));
+    s.reflective = m0.x; s.surf = sq::mk(m0.y, m0.z, m0.w);
+    s.emit = sq::scale(m1.x, sq::mk(m1.y, m1.z, m1.w));
+    return s;
+}
+
+// bounceRay (src/Lib.hs:155-181): x and u are the SAME draw nu (same `gen`); v is the next draw nv.
+__device__ __forceinline__ f3 bounce_dir(f3 d, const Surface& s, uint32_t nu, uint32_t nv) {
+    const float x = sq::unit_float(nu);
+    if (s.reflective < x) {                                             // scatterRay, src/Lib.hs:166-172
+        const float u = x, v = sq::unit_float(nv);
+        const float th = 2 * sq::kPi * u;
+        const float ph = sq::facos(2 * v - 1);
+        float sth, cth, sph, cph;
+        sq::fsincos(th, sth, cth); sq::fsincos(ph, sph, cph);
+        const f3 nd = sq::mk(cth * sph, sth * sph, cph);                // randomVector, src/Lib.hs:192-198
+        const float old_ = sq::hsignum(sq::dot(d, s.n)), new_ = sq::hsignum(sq::dot(nd, s.n));
+        return (old_ == new_) ? -nd : nd;
+    }
+    const f3 dn = sq::normalize(s.n);                                   // reflectRay, src/Lib.hs:176-181
+    return d - sq::scale(2 * sq::dot(dn, d), dn);
+}
+
+// rgbFloatToPixelRGB (src/Lib.hs:93-104).  floor :: Float -> Word8 wraps mod 256 and maps NaN/Inf to 0.
+__device__ __forceinline__ uint8_t to_word8(float f) {
+    if (!(f == f) || f == __builtin_inff() || f == -__builtin_inff()) return 0;
+    const double fl = __builtin_floor((double)f);
+    const double md = fl - 256.0 * __builtin_floor(fl / 256.0);
+    return (uint8_t)(int)md;
+}
+__device__ __forceinline__ void tonemap(f3 c, uint8_t* out) {
+    const float mx = sq::hmax(sq::hmax(c.x, c.y), c.z), mn = sq::hmin(sq::hmin(c.x, c.y), c.z);
+    const float lightness = 0.5f * (mx + mn);
+    const float intensity = sq::fatan(lightness) / (sq::kPi / 2);
+    const f3 s = sq::scale(intensity / mx, c);
+    out[0] = to_word8(s.x * 255); out[1] = to_word8(s.y * 255); out[2] = to_word8(s.z * 255);
+}
+
+// makeRay (src/Lib.hs:107-114) + rotVert (src/Geometry.hs:104-107): dims = (w :. h), ix = (y :. x)
+__device__ __forceinline__ f3 primary_dir(const float* rot, int w, int h, int y, int x) {
+    const float ww = (float)w, hh = (float)h;
+    const float xoffs = ((float)x - (ww / 2)) / ww;
+    const float yoffs = ((hh / 2) - (float)y) / hh;
+    const float v[3] = { 1.0f, xoffs, yoffs };
+    float o[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { float r = 0.0f; for (int k = 0; k < 3; ++k) r = v[k] * rot[3 * k + j] + r; o[j] = r; }
+    return sq::mk(o[0], o[1], o[2]);
+}
+
+// ----------------------------------------------------------------------------------------------
+// intersectBIH (src/BIH.hs:101-141) as a state machine: the reference's recursion with its call
+// stack made explicit.  A frame is one stack word:
+//     FAR(b)      = b            "branch b descended into its near child; the far child is pending"
+//     COMBINE(i)  = i | flag     "the near child of this branch returned the hit on triangle i; combine
+//                                 it with what the far child returns" (src/BIH.hs:115,120)
+// R is the value returned by the most recently finished call.  A COMBINE frame stores only the
+// triangle: its t and dist are recomputed with moller_trumbore, which returns the same bits.
+// NodeSrc supplies branch quads (LDS-staged or global); StackT is uint16_t when indices fit 15 bits.
+// ----------------------------------------------------------------------------------------------
+enum : int { M_DESCEND = 0, M_LEAF = 1, M_UNWIND = 2, M_DONE = 3 };
+
+template <typename StackT> struct StackTraits;
+template <> struct StackTraits<uint16_t> { static constexpr uint32_t flag = 0x8000u; };
+template <> struct StackTraits<uint32_t> { static constexpr uint32_t flag = 0x80000000u; };
+
+struct GlobalNodes {
+    const float4* g;
+    __device__ __forceinline__ float4 quad(uint32_t b, int k) const { return g[3 * b + k]; }
+};
+struct LdsNodes {               // first n_lds branches staged in LDS, the rest read from HBM/L2
+    const float4* l; const float4* g; uint32_t n_lds;
+    __device__ __forceinline__ float4 quad(uint32_t b, int k) const { return b < n_lds ? l[3 * b + k] : g[3 * b + k]; }
+};
+
+struct Trav {
+    f3 o, d, df;
+    uint32_t cur;
+    int sp, mode;
+    Hit R;
+};
+
+template <typename NodeSrc>
+__device__ __forceinline__ void trav_begin(Trav& T, const SceneView& S, f3 o, f3 d) {
+    T.o = o; T.d = d; T.df = sq::mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    T.cur = S.root_ref; T.sp = 0; T.R.t = 0; T.R.dist = 0; T.R.tri = -1;
+    T.mode = (T.cur & kLeafBit) ? M_LEAF : M_DESCEND;
+    if (T.mode == M_DESCEND &&
+        !slab(S.root_lo[0], S.root_lo[1], S.root_lo[2], S.root_hi[0], S.root_hi[1], S.root_hi[2], o, T.df))
+        T.mode = M_DONE;                                                // src/BIH.hs:112 at the root
+}
+
+// One Branch equation (src/BIH.hs:111-141).  Pre: mode == M_DESCEND.
+template <typename NodeSrc, typename StackT>
+__device__ __forceinline__ void trav_descend(Trav& T, const NodeSrc& N, StackT* stk, int stride) {
+    const float4 q0 = N.quad(T.cur, 0), q1 = N.quad(T.cur, 1), q2 = N.quad(T.cur, 2);
+    const int ax = __float_as_int(q2.x);
+    const uint32_t left = __float_as_uint(q2.y), right = __float_as_uint(q2.z);
+    const float lmax = q0.w, rmin = q1.w;
+    // left = bbox with hi[ax] := lmax ; right = bbox with lo[ax] := rmin   (src/BIH.hs:130-141)
+    const bool iL = slab(q0.x, q0.y, q0.z, ax == 0 ? lmax : q1.x, ax == 1 ? lmax : q1.y, ax == 2 ? lmax : q1.z, T.o, T.df);
+    const bool iR = slab(ax == 0 ? rmin : q0.x, ax == 1 ? rmin : q0.y, ax == 2 ? rmin : q0.z, q1.x, q1.y, q1.z, T.o, T.df);
+    if (iL && iR) {
+        const bool l2r = sq::axis_of(T.d, ax) > 0;                      // src/BIH.hs:127
+        stk[T.sp * stride] = (StackT)T.cur; ++T.sp;                     // FAR(cur)
+        T.cur = l2r ? left : right;
+    } else if (iL) T.cur = left;
+    else if (iR) T.cur = right;
+    else { T.R.tri = -1; T.mode = M_UNWIND; return; }                   // src/BIH.hs:119
+    if (T.cur & kLeafBit) T.mode = M_LEAF;
+}
+
+// One triangle of a Leaf equation folded into R with minimumBy's rule (src/BIH.hs:105-109).
+__device__ __forceinline__ void leaf_fold(Trav& T, const SceneView& S, int i) {
+    const float4 a = S.tris[3 * i], b = S.tris[3 * i + 1], c = S.tris[3 * i + 2];
+    float t, dist;
+    if (moller_trumbore(T.o, T.d, sq::mk(a.x, a.y, a.z), sq::mk(b.x, b.y, b.z), sq::mk(c.x, c.y, c.z), t, dist)) {
+        if (T.R.tri < 0 || sq::cmp_gt(T.R.dist, dist)) { T.R.t = t; T.R.dist = dist; T.R.tri = i; }   // replace only on GT
+    }
+}
+// The whole Leaf equation.  Pre: mode == M_LEAF.
+__device__ __forceinline__ void trav_leaf(Trav& T, const SceneView& S) {
+    const int2 lf = S.leaves[T.cur & ~kLeafBit];
+    T.R.tri = -1;
+    for (int i = lf.x; i < lf.x + lf.y; ++i) leaf_fold(T, S, i);
+    T.mode = M_UNWIND;
+}
+
+// Return to the caller of the call that just produced R: pop one frame.  Pre: mode == M_UNWIND.
+template <typename NodeSrc, typename StackT>
+__device__ __forceinline__ void trav_unwind(Trav& T, const SceneView& S, const NodeSrc& N, StackT* stk, int stride) {
+    constexpr uint32_t flag = StackTraits<StackT>::flag;
+    if (T.sp == 0) { T.mode = M_DONE; return; }
+    --T.sp;
+    const uint32_t e = stk[T.sp * stride];
+    if (e & flag) {                                                     // minimumByMay over [near, far] (src/BIH.hs:115,120)
+        const int32_t ntri = (int32_t)(e & ~flag);
+        const float4 a = S.tris[3 * ntri], b = S.tris[3 * ntri + 1], c = S.tris[3 * ntri + 2];
+        float nt = 0, ndist = 0;
+        (void)moller_trumbore(T.o, T.d, sq::mk(a.x, a.y, a.z), sq::mk(b.x, b.y, b.z), sq::mk(c.x, c.y, c.z), nt, ndist);
+        if (T.R.tri < 0 || !sq::cmp_gt(ndist, T.R.dist)) { T.R.t = nt; T.R.dist = ndist; T.R.tri = ntri; }   // ties keep near
+        return;
+    }
+    const float4 q0 = N.quad(e, 0), q1 = N.quad(e, 1), q2 = N.quad(e, 2);  // back in branch e: its near child returned R
+    const int ax = __float_as_int(q2.x);
+    const bool l2r = sq::axis_of(T.d, ax) > 0;
+    if (T.R.tri >= 0) {
+        const float p = sq::axis_of(T.o, ax) + T.R.t * sq::axis_of(T.d, ax);   // projectToAxis ax (intersectPoint near)
+        const bool close = l2r ? (p < q1.w) : (p > q0.w);               // isClose, src/BIH.hs:121-123
+        if (close) return;                                              // src/BIH.hs:114: the branch returns near
+        stk[T.sp * stride] = (StackT)((uint32_t)T.R.tri | flag); ++T.sp;   // COMBINE(R)
+    }
+    T.cur = l2r ? __float_as_uint(q2.z) : __float_as_uint(q2.y);        // the far child
+    T.mode = (T.cur & kLeafBit) ? M_LEAF : M_DESCEND;
+}
+
+// Whole query, one ray per lane (used where rays of a wave are coherent: primary and shadow rays).
+template <typename NodeSrc, typename StackT>
+__device__ __forceinline__ Hit trace_one(const SceneView& S, const NodeSrc& N, f3 o, f3 d, StackT* stk, int stride) {
+    Trav T;
+    trav_begin<NodeSrc>(T, S, o, d);
+    while (T.mode != M_DONE) {
+        while (T.mode == M_DESCEND) trav_descend(T, N, stk, stride);
+        if (T.mode == M_LEAF) trav_leaf(T, S);
+        while (T.mode == M_UNWIND) trav_unwind(T, S, N, stk, stride);
+    }
+    return T.R;
+}
+
+}  // namespace sqd

@@ -130,6 +130,27 @@ def test_sharded_render_equals_unsharded(sqt, product_scene, dev):
         assert torch.equal(frame.view(torch.int32), full.view(torch.int32)) and torch.equal(frame8, full8)
 
 
+@pytest.mark.parametrize("w,h,n,slots", [(120, 90, 9, 120 * 90 * 2), (64, 200, 5, 1 << 20)])
+def test_kernel_variants_agree(sqt, product_scene, oracle_scene, dev, w, h, n, slots):
+    """The one-lane-per-pixel kernel (variant 1) and the wavefront pipeline (variant 2, also with several
+    sample batches) produce identical bits, and both equal the oracle."""
+    import torch
+    bih, cam, _ = product_scene
+    ob, ocam, _ = oracle_scene
+    outs = []
+    for variant in (1, 2):
+        dev.set_option("variant", variant)
+        dev.set_option("slots", slots)
+        a, r = dev.render_rows(cam, n, w, h)
+        torch.cuda.synchronize()
+        outs.append((a.cpu().numpy(), r.cpu().numpy()))
+    dev.set_option("variant", 2)
+    dev.set_option("slots", 48 << 20)
+    o, o8, _ = ob.render(ocam, n, w, h, threads=THREADS)
+    for a, r in outs:
+        assert np.array_equal(bits(a), bits(o)) and np.array_equal(r, o8)
+
+
 def test_c_abi_error_behaviour(sqt, product_scene):
     bih, cam, _ = product_scene
     for dims, n in [((0, 4), 1), ((4, 0), 1), ((4, 4), 0), ((-1, 4), 1)]:

@@ -14,19 +14,36 @@ cam = sqt.load_camera(os.path.join(data, "camera"))
 ob = O.BIH(O.tris_from_obj(os.path.join(data, "scene.obj"), data))
 oc = O.load_camera(os.path.join(data, "camera"))
 ok = True
-for (w, h, n, cast) in [(64, 64, 4, False), (48, 80, 3, False), (64, 64, 2, True), (96, 96, 16, False)]:
-    g_avg = sqt.render_f32(bih, cam, n, (w, h), cast)
-    g_rgb = sqt.render_rgb8(bih, cam, n, (w, h), cast)
-    o_avg, o_rgb, _ = ob.render(oc, n, w, h, cast=cast, threads=os.cpu_count())
-    same = np.array_equal(g_avg.view(np.uint32), o_avg.view(np.uint32))
-    same8 = np.array_equal(g_rgb, o_rgb)
-    nd = int((g_avg.view(np.uint32) != o_avg.view(np.uint32)).any(-1).sum())
-    print(f"{w}x{h} n={n} cast={cast}: avg bit-equal={same} rgb equal={same8} differing pixels={nd} maxabs={np.abs(g_avg-o_avg).max():.3g}", flush=True)
-    ok &= same and same8
 ds = sqt.DeviceScene(bih, 0)
-for (w, h, n) in [(256, 256, 4), (540, 540, 16), (1920, 1080, 16)]:
-    torch.cuda.synchronize(); ds.reset_timing()
-    t = time.time(); ds.render_rows(cam, n, w, h); torch.cuda.synchronize(); dt = time.time() - t
-    ms, cnt, name = ds.kernel_timing()
-    print(f"{w}x{h}@{n}: wall {dt*1e3:.1f} ms, kernel {ms:.1f} ms, {w*h*n/ms/1e3:.1f} Msamples/s", flush=True)
+for (w, h, n, cast) in [(64, 64, 4, False), (48, 80, 3, False), (64, 64, 2, True), (96, 96, 16, False), (200, 120, 33, False)]:
+    o_avg, o_rgb, _ = ob.render(oc, n, w, h, cast=cast, threads=16)
+    for variant in (1, 2):
+        ds.set_option("variant", variant)
+        if variant == 2:
+            ds.set_option("slots", w * h * 5)        # force several batches
+        a, r = ds.render_rows(cam, n, w, h, cast=cast); torch.cuda.synchronize()
+        g_avg, g_rgb = a.cpu().numpy(), r.cpu().numpy()
+        same = np.array_equal(g_avg.view(np.uint32), o_avg.view(np.uint32)); same8 = np.array_equal(g_rgb, o_rgb)
+        nd = int((g_avg.view(np.uint32) != o_avg.view(np.uint32)).any(-1).sum())
+        print(f"{w}x{h} n={n} cast={cast} variant={variant}: avg bit-equal={same} rgb equal={same8} differing pixels={nd} maxabs={np.abs(g_avg-o_avg).max():.3g}", flush=True)
+        ok &= same and same8
+ds.set_option("slots", 48 << 20)
+args = [a for a in sys.argv[1:]]
+for variant in (1, 2):
+    ds.set_option("variant", variant)
+    for (w, h, n) in [(256, 256, 4), (540, 540, 64), (1920, 1080, 64)]:
+        ds.render_rows(cam, n, w, h); torch.cuda.synchronize(); ds.reset_timing()
+        t = time.time(); ds.render_rows(cam, n, w, h); torch.cuda.synchronize(); dt = time.time() - t
+        ms, cnt, name = ds.kernel_timing()
+        print(f"variant {variant} {w}x{h}@{n}: wall {dt*1e3:.1f} ms -> {w*h*n/dt/1e6:.1f} Msamples/s   [{name}: {cnt} launches, {ms*cnt:.1f} ms total]", flush=True)
+if "sweep" in args:
+    ds.set_option("variant", 2)
+    w, h, n = 1920, 1080, 64
+    for strag in (0, 4, 8, 12, 16, 24, 32, 48):
+        for bpc in (1, 2, 3, 4):
+            ds.set_option("straggler_lanes", strag); ds.set_option("trace_blocks_per_cu", bpc)
+            ds.render_rows(cam, n, w, h); torch.cuda.synchronize(); ds.reset_timing()
+            t = time.time(); ds.render_rows(cam, n, w, h); torch.cuda.synchronize(); dt = time.time() - t
+            ms, cnt, name = ds.kernel_timing()
+            print(f"straggler={strag} blocks/cu={bpc}: {w*h*n/dt/1e6:.1f} Msamples/s (trace {ms*cnt:.1f} ms of {dt*1e3:.1f})", flush=True)
 sys.exit(0 if ok else 1)

@@ -1,0 +1,32 @@
+#!/bin/bash
+# Collect rocprofv3 PMC counters for the render kernel in separate passes (never combined with tracing).
+# usage: tools/pmc_profile.sh <tag> [bench args...]   (run on the GPU box via gpurun)
+set -u
+TAG=$1; shift
+OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+cd $GRAFT_REPO_ROOT
+i=0
+for CTRS in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
+            "SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_ANY" \
+            "SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_LEVEL_WAVES SQ_ACTIVE_INST_SCA SQ_INSTS_BRANCH SQ_ACTIVE_INST_MISC SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_FMA_F64" \
+            "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" \
+            "FETCH_SIZE" "WRITE_SIZE"; do
+  i=$((i+1))
+  timeout -k 10 300 rocprofv3 --pmc $CTRS --kernel-include-regex sq_render --output-format csv -d $OUT/pass$i -- python bench.py --no-cpu "$@" > $OUT/pass$i.log 2>&1
+  echo "pass $i ($CTRS) rc=$?"
+done
+python - <<PY
+import csv, glob, collections
+tot = collections.OrderedDict()
+n = 0
+for f in sorted(glob.glob("$OUT/pass*/*/*counter_collection.csv")):
+    for r in csv.DictReader(open(f)):
+        if "sq_render" not in r["Kernel_Name"]: continue
+        tot.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+with open("$OUT/summary.txt", "w") as o:
+    for k, v in tot.items():
+        line = f"{k:32s} launches={len(v)} mean_per_launch={sum(v)/len(v):.6g}"
+        print(line); o.write(line + "\n")
+PY
