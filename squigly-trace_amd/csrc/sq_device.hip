@@ -21,6 +21,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/squigly_hip.h"
@@ -37,8 +39,9 @@ using namespace sqd;
     } while (0)
 
 constexpr int kBlock = 256;        // per-pixel / per-sample kernels
-constexpr int kTraceBlock = 512;   // persistent trace kernel: 8 waves share one LDS copy of the nodes
-constexpr int kChunk = 256;        // rays a wave reserves from the queue per atomic
+constexpr int kTraceBlock = 512;   // persistent trace kernel, streaming form: 8 waves share one LDS copy of the top of the tree
+constexpr int kResidentBlock = 1024; // persistent trace kernel, resident form: one workgroup per CU owns the whole scene in LDS
+constexpr int kChunk = 128;        // rays a wave reserves from the queue per atomic
 
 // ----------------------------------------------------------------------------------------------
 // Frame description shared by the kernels
@@ -62,7 +65,7 @@ __device__ __forceinline__ void pixel_coords(const Frame& F, long long pix, int&
 template <typename StackT>
 __global__ void __launch_bounds__(kBlock) sq_render_pixels(const SceneView S, const Frame F) {
     extern __shared__ float4 lds_raw[];
-    StackT* stk = reinterpret_cast<StackT*>(lds_raw) + threadIdx.x;
+    SQ_LDS StackT* stk = to_lds<StackT>(lds_raw) + threadIdx.x;
     const long long pix = (long long)blockIdx.x * kBlock + threadIdx.x;
     if (pix >= (long long)F.local_rows * F.h) return;
     int y, x; pixel_coords(F, pix, y, x);
@@ -119,18 +122,18 @@ struct Work {                 // device workspace of one frame (HBM)
     float*   px_t0;           // primary hit: t
     int32_t* px_tri0;         // primary hit: triangle
     float*   px_sum;          // running ordered sum of sample radiances, 3 floats
-    // per sample slot sid = k_local * A + a
+    // per sample slot sid = k_local * A + a : the ray queue is dense in sid, dead entries are flagged
+    float4*  org;             // ray origin.xyz ; w = kLive / kDead
+    float4*  dir;             // ray direction.xyz ; w = triangle hit by ray 1 (second bounce level)
+    int2*    hit;             // (t bits, tri) of the ray currently in the slot
     uint2*   rng12;           // (n1, n2) of the sample's generator
     float*   rad;             // finished sample radiance, 3 floats
-    // ray queues (two bounce levels): org.xyz + sid, dir.xyz + aux
-    float4 *q_org[2], *q_dir[2];
-    int2*   q_hit[2];         // (t bits, tri) per queue entry
-    int32_t* q_count[2];      // device counters
-    int32_t* q_head[2];       // dequeue cursors of the persistent trace kernel
+    int32_t* head[2];         // dequeue cursors of the persistent trace kernel, one per bounce level
     int64_t  slot_capacity;
 };
+constexpr float kLive = 1.0f, kDead = -1.0f;
 
-// Appends `want` lanes of this wave to a queue with one atomic: wave ballot + prefix rank.
+// Appends `want` lanes of this wave to a list with one atomic: wave ballot + prefix rank.
 __device__ __forceinline__ int wave_append(int32_t* counter, bool want) {
     const unsigned long long m = __ballot(want);
     if (m == 0) return -1;
@@ -146,7 +149,7 @@ __device__ __forceinline__ int wave_append(int32_t* counter, bool want) {
 template <typename StackT>
 __global__ void __launch_bounds__(kBlock) sq_primary(const SceneView S, const Frame F, const Work W) {
     extern __shared__ float4 lds_raw[];
-    StackT* stk = reinterpret_cast<StackT*>(lds_raw) + threadIdx.x;
+    SQ_LDS StackT* stk = to_lds<StackT>(lds_raw) + threadIdx.x;
     const long long pix = (long long)blockIdx.x * kBlock + threadIdx.x;
     const bool in = pix < (long long)F.local_rows * F.h;
     Hit h0; h0.tri = -1; h0.t = 0; h0.dist = 0;
@@ -177,95 +180,77 @@ __device__ __forceinline__ Pixel0 load_pixel0(const SceneView& S, const Frame& F
 __device__ __forceinline__ bool absorbs(const SceneView& S, const Surface& s) {
     return S.nonneg_materials && s.surf.x == 0.0f && s.surf.y == 0.0f && s.surf.z == 0.0f;
 }
+__device__ __forceinline__ void store_rad(const Work& W, long long sid, f3 L) {
+    W.rad[3 * sid] = L.x; W.rad[3 * sid + 1] = L.y; W.rad[3 * sid + 2] = L.z;
+}
 
-// Depth-0 bounce of every sample of the batch: RNG, bounceRay, enqueue ray 1 (src/Lib.hs:133-134).
+// Depth-0 bounce of every sample of the batch: RNG, bounceRay, ray 1 into slot sid (src/Lib.hs:133-134).
 __global__ void __launch_bounds__(kBlock) sq_gen_bounce1(const SceneView S, const Frame F, const Work W, int k_base, int k_count) {
     const int A = *W.n_active;
     const long long total = (long long)A * k_count;
-    const long long stride = (long long)gridDim.x * kBlock;
-    // every lane of a wave runs the same number of iterations so that wave_append sees whole waves
-    const long long iters = (total + stride - 1) / stride;
-    for (long long it = 0; it < iters; ++it) {
-        const long long sid = it * stride + (long long)blockIdx.x * kBlock + threadIdx.x;
-        const bool live = sid < total;
-        bool want = false; f3 d1 = sq::mk(0, 0, 0); Pixel0 P{};
-        if (live) {
-            const int a = (int)(sid % A), k = k_base + (int)(sid / A);
-            P = load_pixel0(S, F, W, a);
-            if (absorbs(S, P.s0)) {
-                const f3 L0 = P.s0.surf * sq::mk(0, 0, 0) + P.s0.emit;
-                W.rad[3 * sid] = L0.x; W.rad[3 * sid + 1] = L0.y; W.rad[3 * sid + 2] = L0.z;
-            } else {
-                const long long rix = (long long)F.samples * ((long long)P.x + (long long)P.y * (long long)F.w);   // src/Lib.hs:85
-                uint32_t n0, n1, n2;
-                sq::tfgen3(rix + k, n0, n1, n2);                        // mkTFGen (rix + k), src/Lib.hs:86
-                W.rng12[sid] = make_uint2(n1, n2);
-                d1 = bounce_dir(P.d0, P.s0, n0, n1);
-                want = true;
-            }
+    for (long long sid = (long long)blockIdx.x * kBlock + threadIdx.x; sid < total; sid += (long long)gridDim.x * kBlock) {
+        const int a = (int)(sid % A), k = k_base + (int)(sid / A);
+        const Pixel0 P = load_pixel0(S, F, W, a);
+        if (absorbs(S, P.s0)) {
+            store_rad(W, sid, P.s0.surf * sq::mk(0, 0, 0) + P.s0.emit);
+            W.org[sid] = make_float4(0, 0, 0, kDead);
+            continue;
         }
-        const int q = wave_append(W.q_count[0], want);
-        if (q >= 0) {
-            W.q_org[0][q] = make_float4(P.p0.x, P.p0.y, P.p0.z, __int_as_float((int)sid));
-            W.q_dir[0][q] = make_float4(d1.x, d1.y, d1.z, 0.0f);
-        }
+        const long long rix = (long long)F.samples * ((long long)P.x + (long long)P.y * (long long)F.w);   // src/Lib.hs:85
+        uint32_t n0, n1, n2;
+        sq::tfgen3(rix + k, n0, n1, n2);                                // mkTFGen (rix + k), src/Lib.hs:86
+        W.rng12[sid] = make_uint2(n1, n2);
+        const f3 d1 = bounce_dir(P.d0, P.s0, n0, n1);
+        W.org[sid] = make_float4(P.p0.x, P.p0.y, P.p0.z, kLive);
+        W.dir[sid] = make_float4(d1.x, d1.y, d1.z, 0.0f);
     }
 }
 
-// After ray 1: a miss finishes the sample; a hit either finishes it (absorbing surface) or enqueues ray 2.
-__global__ void __launch_bounds__(kBlock) sq_shade1(const SceneView S, const Frame F, const Work W) {
+// After ray 1: a miss finishes the sample; a hit either finishes it (absorbing surface) or puts ray 2 in the slot.
+__global__ void __launch_bounds__(kBlock) sq_shade1(const SceneView S, const Frame F, const Work W, int k_count) {
     const int A = *W.n_active;
-    const int total = *W.q_count[0];
-    const long long stride = (long long)gridDim.x * kBlock;
-    const long long iters = (total + stride - 1) / stride;
-    for (long long it = 0; it < iters; ++it) {
-        const long long q = it * stride + (long long)blockIdx.x * kBlock + threadIdx.x;
-        bool want = false; f3 p1 = sq::mk(0, 0, 0), d2 = sq::mk(0, 0, 0); int sid = 0, tri1 = -1;
-        if (q < total) {
-            const float4 org = W.q_org[0][q], dir = W.q_dir[0][q];
-            const int2 hit = W.q_hit[0][q];
-            sid = __float_as_int(org.w); tri1 = hit.y;
-            if (tri1 < 0) {                                             // raytrace ... 1 = black
-                const Surface s0 = surface_of(S, W.px_tri0[sid % A]);
-                const f3 L0 = s0.surf * sq::mk(0, 0, 0) + s0.emit;
-                W.rad[3 * sid] = L0.x; W.rad[3 * sid + 1] = L0.y; W.rad[3 * sid + 2] = L0.z;
-            } else {
-                const Surface s1 = surface_of(S, tri1);
-                if (absorbs(S, s1)) {
-                    const Surface s0 = surface_of(S, W.px_tri0[sid % A]);
-                    const f3 L1 = s1.surf * sq::mk(0, 0, 0) + s1.emit;
-                    const f3 L0 = s0.surf * L1 + s0.emit;
-                    W.rad[3 * sid] = L0.x; W.rad[3 * sid + 1] = L0.y; W.rad[3 * sid + 2] = L0.z;
-                } else {
-                    const f3 d1 = sq::mk(dir.x, dir.y, dir.z);
-                    p1 = sq::mk(org.x, org.y, org.z) + sq::scale(__int_as_float(hit.x), d1);
-                    const uint2 r = W.rng12[sid];
-                    d2 = bounce_dir(d1, s1, r.x, r.y);                  // gen advanced by one: x = u = p(n1), v = p(n2)
-                    want = true;
-                }
-            }
+    const long long total = (long long)A * k_count;
+    for (long long sid = (long long)blockIdx.x * kBlock + threadIdx.x; sid < total; sid += (long long)gridDim.x * kBlock) {
+        const float4 org = W.org[sid];
+        if (org.w < 0) continue;
+        const int2 hit = W.hit[sid];
+        const int tri1 = hit.y;
+        if (tri1 < 0) {                                                 // raytrace ... 1 = black
+            const Surface s0 = surface_of(S, W.px_tri0[sid % A]);
+            store_rad(W, sid, s0.surf * sq::mk(0, 0, 0) + s0.emit);
+            W.org[sid].w = kDead;
+            continue;
         }
-        const int q2 = wave_append(W.q_count[1], want);
-        if (q2 >= 0) {
-            W.q_org[1][q2] = make_float4(p1.x, p1.y, p1.z, __int_as_float(sid));
-            W.q_dir[1][q2] = make_float4(d2.x, d2.y, d2.z, __int_as_float(tri1));
+        const Surface s1 = surface_of(S, tri1);
+        if (absorbs(S, s1)) {
+            const Surface s0 = surface_of(S, W.px_tri0[sid % A]);
+            const f3 L1 = s1.surf * sq::mk(0, 0, 0) + s1.emit;
+            store_rad(W, sid, s0.surf * L1 + s0.emit);
+            W.org[sid].w = kDead;
+            continue;
         }
+        const float4 dir = W.dir[sid];
+        const f3 d1 = sq::mk(dir.x, dir.y, dir.z);
+        const f3 p1 = sq::mk(org.x, org.y, org.z) + sq::scale(__int_as_float(hit.x), d1);
+        const uint2 r = W.rng12[sid];
+        const f3 d2 = bounce_dir(d1, s1, r.x, r.y);                     // gen advanced by one: x = u = p(n1), v = p(n2)
+        W.org[sid] = make_float4(p1.x, p1.y, p1.z, kLive);
+        W.dir[sid] = make_float4(d2.x, d2.y, d2.z, __int_as_float(tri1));
     }
 }
 
 // After ray 2: L2 = s2*0 + e2 (or black), L1 = s1*L2 + e1, L0 = s0*L1 + e0   (src/Lib.hs:135-137)
-__global__ void __launch_bounds__(kBlock) sq_shade2(const SceneView S, const Frame F, const Work W) {
+__global__ void __launch_bounds__(kBlock) sq_shade2(const SceneView S, const Frame F, const Work W, int k_count) {
     const int A = *W.n_active;
-    const int total = *W.q_count[1];
-    for (long long q = (long long)blockIdx.x * kBlock + threadIdx.x; q < total; q += (long long)gridDim.x * kBlock) {
-        const int sid = __float_as_int(W.q_org[1][q].w), tri1 = __float_as_int(W.q_dir[1][q].w);
-        const int tri2 = W.q_hit[1][q].y;
+    const long long total = (long long)A * k_count;
+    for (long long sid = (long long)blockIdx.x * kBlock + threadIdx.x; sid < total; sid += (long long)gridDim.x * kBlock) {
+        if (W.org[sid].w < 0) continue;
+        const int tri1 = __float_as_int(W.dir[sid].w), tri2 = W.hit[sid].y;
         f3 L2 = sq::mk(0, 0, 0);
         if (tri2 >= 0) { const Surface s2 = surface_of(S, tri2); L2 = s2.surf * sq::mk(0, 0, 0) + s2.emit; }
         const Surface s1 = surface_of(S, tri1), s0 = surface_of(S, W.px_tri0[sid % A]);
         const f3 L1 = s1.surf * L2 + s1.emit;
-        const f3 L0 = s0.surf * L1 + s0.emit;
-        W.rad[3 * sid] = L0.x; W.rad[3 * sid + 1] = L0.y; W.rad[3 * sid + 2] = L0.z;
+        store_rad(W, sid, s0.surf * L1 + s0.emit);
     }
 }
 
@@ -286,29 +271,68 @@ __global__ void __launch_bounds__(kBlock) sq_accumulate(const Frame F, const Wor
     }
 }
 
-// The dominant kernel.  Persistent: each wave reserves chunks of the ray queue with one atomic and
-// each lane starts its next ray as soon as the previous one is finished, so a wave's lanes stay
-// busy although ray lengths differ by 10x.  The first n_lds branches (breadth-first = the top of
-// the tree) are staged in LDS once per workgroup; every lane keeps its frame stack in LDS
-// (lane-minor layout, one word per frame, at most height-1 frames).
+// The dominant kernel.  Persistent: each wave reserves a chunk of the (dense) ray queue with one
+// atomic, compacts the chunk's live entries with ballots into a small LDS list, and each lane pulls
+// its next ray from that list as soon as the previous one is finished, so a wave's lanes stay busy
+// although ray lengths differ by 10x and although part of the queue is dead.  The first n_lds
+// branches (breadth-first = the top of the tree) are staged in LDS once per workgroup; every lane
+// keeps its frame stack in LDS (lane-minor layout, one word per frame, at most height-1 frames).
 struct TraceArgs {
     const float4* org; const float4* dir; int2* hits;
-    const int32_t* n_rays; int32_t* head;
+    const int32_t* n_active; int32_t k_count; int32_t* head;
     int32_t n_lds; int32_t stack_cap; int32_t straggler_lanes;
 };
-template <typename StackT>
-__global__ void __launch_bounds__(kTraceBlock) sq_trace_rays(const SceneView S, const TraceArgs A) {
+// LDS carve-up of the trace kernel (bytes, all 16-B aligned), shared by host and device.
+struct TraceLds { uint32_t nodes, leaves, verts, trix, live, stack, total; };
+__host__ __device__ inline TraceLds trace_lds_layout(int n_lds, bool resident, int n_leaves, int n_verts, int n_tris,
+                                                     int block, int stack_cap, int stack_elem) {
+    auto al = [](uint32_t b) { return (b + 15u) & ~15u; };
+    TraceLds L; uint32_t off = 0;
+    L.nodes = off;  off += al((uint32_t)n_lds * 48u);
+    L.leaves = off; off += resident ? al((uint32_t)n_leaves * 8u) : 0u;
+    L.verts = off;  off += resident ? al((uint32_t)n_verts * 12u) : 0u;
+    L.trix = off;   off += resident ? al((uint32_t)n_tris * 8u) : 0u;
+    L.live = off;   off += al((uint32_t)(block / 64) * kChunk * 2u);
+    L.stack = off;  off += al((uint32_t)block * (uint32_t)stack_cap * (uint32_t)stack_elem);
+    L.total = off;
+    return L;
+}
+
+template <typename StackT, bool RESIDENT, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) sq_trace_rays(const SceneView S, const TraceArgs A) {
     extern __shared__ float4 lds_raw[];
-    float4* lnodes = lds_raw;
-    StackT* stk = reinterpret_cast<StackT*>(lds_raw + 3 * (size_t)A.n_lds) + threadIdx.x;
-    for (int i = threadIdx.x; i < 3 * A.n_lds; i += kTraceBlock) lnodes[i] = S.branches[i];   // coalesced 16-B loads
+    char* lds = reinterpret_cast<char*>(lds_raw);
+    const TraceLds L = trace_lds_layout(A.n_lds, RESIDENT, S.n_leaves, S.n_verts, S.n_tris, BLOCK, A.stack_cap, (int)sizeof(StackT));
+    SQ_LDS v4f* lnodes = to_lds<v4f>(lds + L.nodes);
+    SQ_LDS uint16_t* live = to_lds<uint16_t>(lds + L.live) + (threadIdx.x >> 6) * kChunk;   // this wave's list
+    SQ_LDS StackT* stk = to_lds<StackT>(lds + L.stack) + threadIdx.x;
+    for (int i = threadIdx.x; i < 3 * A.n_lds; i += BLOCK) { const float4 q = S.branches[i]; lnodes[i] = v4f{ q.x, q.y, q.z, q.w }; }   // coalesced 16-B loads
+    if (RESIDENT) {
+        SQ_LDS v2i* ll = to_lds<v2i>(lds + L.leaves);
+        SQ_LDS float* lv = to_lds<float>(lds + L.verts);
+        SQ_LDS v4us* lt = to_lds<v4us>(lds + L.trix);
+        for (int i = threadIdx.x; i < S.n_leaves; i += BLOCK) { const int2 l = S.leaves[i]; ll[i] = v2i{ l.x, l.y }; }
+        for (int i = threadIdx.x; i < 3 * S.n_verts; i += BLOCK) lv[i] = S.verts[i];
+        for (int i = threadIdx.x; i < S.n_tris; i += BLOCK) { const ushort4 t = S.trix[i]; lt[i] = v4us{ t.x, t.y, t.z, t.w }; }
+    }
     __syncthreads();
-    const LdsNodes N{ lnodes, S.branches, (uint32_t)A.n_lds };
-    const int n = *A.n_rays;
+    using NodeSrc = typename std::conditional<RESIDENT, LdsNodes, HybridNodes>::type;
+    using TriSrc = typename std::conditional<RESIDENT, LdsTris, GlobalTris>::type;
+    NodeSrc N; TriSrc G;
+    if constexpr (RESIDENT) {
+        N = LdsNodes{ lnodes };
+        G = LdsTris{ to_lds<float>(lds + L.verts), to_lds<v4us>(lds + L.trix), to_lds<v2i>(lds + L.leaves) };
+    } else {
+        N = HybridNodes{ lnodes, S.branches, (uint32_t)A.n_lds };
+        G = GlobalTris{ S.tris, S.leaves };
+    }
+    const long long n = (long long)(*A.n_active) * A.k_count;
     const int lane = threadIdx.x & 63;
-    int chunk_cur = 0, chunk_end = 0;       // wave-uniform
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    long long chunk_base = 0;               // wave-uniform
+    int list_pos = 0, list_len = 0;         // wave-uniform
     bool exhausted = false;                 // wave-uniform
-    int my_ray = -1;
+    long long my_ray = -1;
     Trav T; T.mode = M_DONE; T.sp = 0; T.cur = 0; T.R.tri = -1; T.R.t = 0; T.R.dist = 0;
     T.o = T.d = T.df = sq::mk(0, 0, 0);
     for (;;) {
@@ -316,22 +340,33 @@ __global__ void __launch_bounds__(kTraceBlock) sq_trace_rays(const SceneView S, 
         if (idle && my_ray >= 0) { A.hits[my_ray] = make_int2(__float_as_int(T.R.t), T.R.tri); my_ray = -1; }
         const unsigned long long m = __ballot(idle);
         if (m) {
-            if (!exhausted && chunk_cur == chunk_end) {
+            while (!exhausted && list_pos == list_len) {                        // reserve and compact the next chunk
                 int base = 0;
                 if (lane == 0) base = atomicAdd(A.head, kChunk);
                 base = __builtin_amdgcn_readfirstlane(base);
-                if (base >= n) exhausted = true;
-                else { chunk_cur = base; chunk_end = min(base + kChunk, n); }
+                if (base >= n) { exhausted = true; break; }
+                chunk_base = base; list_pos = 0; list_len = 0;
+#pragma unroll
+                for (int j = 0; j < kChunk / 64; ++j) {
+                    const long long idx = chunk_base + j * 64 + lane;
+                    const bool alive = idx < n && A.org[idx].w >= 0.0f;
+                    const unsigned long long am = __ballot(alive);
+                    if (alive) live[list_len + __popcll(am & lt_mask)] = (uint16_t)(j * 64 + lane);
+                    list_len += __popcll(am);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
             if (!exhausted) {
-                const int rank = __popcll(m & ((1ull << lane) - 1ull));
-                const int avail = chunk_end - chunk_cur;
+                const int rank = __popcll(m & lt_mask);
+                const int avail = list_len - list_pos;
                 if (idle && rank < avail) {
-                    my_ray = chunk_cur + rank;
+                    my_ray = chunk_base + live[list_pos + rank];
                     const float4 o = A.org[my_ray], d = A.dir[my_ray];
-                    trav_begin<LdsNodes>(T, S, sq::mk(o.x, o.y, o.z), sq::mk(d.x, d.y, d.z));
+                    trav_begin<NodeSrc>(T, S, sq::mk(o.x, o.y, o.z), sq::mk(d.x, d.y, d.z));
                 }
-                chunk_cur += min(__popcll(m), avail);
+                list_pos += min(__popcll(m), avail);
             } else if (m == ~0ull) break;
         }
         // advance until (almost) every lane has a leaf to test or is finished
@@ -340,10 +375,10 @@ __global__ void __launch_bounds__(kTraceBlock) sq_trace_rays(const SceneView S, 
             const unsigned long long am = __ballot(adv);
             if (am == 0) break;
             if (__popcll(am) <= A.straggler_lanes && __ballot(T.mode == M_LEAF) != 0) break;
-            if (T.mode == M_DESCEND) trav_descend(T, N, stk, kTraceBlock);
-            else if (T.mode == M_UNWIND) trav_unwind(T, S, N, stk, kTraceBlock);
+            if (T.mode == M_UNWIND) trav_unwind(T, N, G, stk, BLOCK);
+            if (T.mode == M_DESCEND) trav_descend(T, N, stk, BLOCK);
         }
-        if (T.mode == M_LEAF) trav_leaf(T, S);
+        if (T.mode == M_LEAF) trav_leaf(T, G);
     }
 }
 
@@ -375,7 +410,7 @@ __global__ void sq_debug_kernel(int op, const void* a, const void* b, long long 
 struct sq_device_scene {
     int device = 0;
     SceneView view{};
-    void *d_branches = nullptr, *d_leaves = nullptr, *d_tris = nullptr, *d_mats = nullptr;
+    void *d_branches = nullptr, *d_leaves = nullptr, *d_tris = nullptr, *d_mats = nullptr, *d_verts = nullptr, *d_trix = nullptr;
     int height = 0; bool small_index = false; int n_cu = 256;
     // workspace (grow-only)
     Work work{}; void* d_work = nullptr; size_t work_bytes = 0; int64_t work_pixels = 0, work_slots = 0;
@@ -383,7 +418,7 @@ struct sq_device_scene {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
     double total_ms = 0; int64_t launches = 0;
     // options
-    int64_t opt_timing = 1, opt_variant = 2, opt_slots = 48ll << 20, opt_straggler = 12, opt_trace_blocks_per_cu = 0;
+    int64_t opt_timing = 1, opt_variant = 2, opt_slots = 48ll << 20, opt_straggler = 6, opt_trace_blocks_per_cu = 0, opt_resident = 1;
     const char* last_kernel = "sq_trace_rays";
 };
 
@@ -492,6 +527,35 @@ extern "C" int sq_scene_upload(const sq_scene* sc, int32_t device, sq_device_sce
         const float comp[8] = { m.reflective, m.surf[0], m.surf[1], m.surf[2], m.emissive, m.emit[0], m.emit[1], m.emit[2] };
         for (float c : comp) { uint32_t bits; std::memcpy(&bits, &c, 4); if ((bits >> 31) || !(c == c) || c > 3.0e38f) nonneg = false; }
     }
+    // Indexed form for LDS residency: unique vertices (bitwise) + 16-bit indices, when they fit.
+    std::vector<float> uverts; std::vector<uint16_t> trix;
+    {
+        struct Key { uint32_t a, b, c; bool operator==(const Key& o) const { return a == o.a && b == o.b && c == o.c; } };
+        struct KeyHash { size_t operator()(const Key& k) const { return ((size_t)k.a * 0x9E3779B1u) ^ ((size_t)k.b * 0x85EBCA77u) ^ ((size_t)k.c * 0xC2B2AE3Du); } };
+        std::unordered_map<Key, uint32_t, KeyHash> ids;
+        bool fits = sc->n_mats <= 65535;
+        std::vector<uint32_t> idx((size_t)sc->n_tris * 3);
+        for (int32_t i = 0; i < sc->n_tris && fits; ++i) {
+            const float* vs[3] = { sc->tris[i].v0, sc->tris[i].v1, sc->tris[i].v2 };
+            for (int k = 0; k < 3; ++k) {
+                Key key; std::memcpy(&key.a, &vs[k][0], 4); std::memcpy(&key.b, &vs[k][1], 4); std::memcpy(&key.c, &vs[k][2], 4);
+                auto it = ids.find(key);
+                if (it == ids.end()) {
+                    if (ids.size() >= 65535) { fits = false; break; }
+                    it = ids.emplace(key, (uint32_t)ids.size()).first;
+                    uverts.insert(uverts.end(), vs[k], vs[k] + 3);
+                }
+                idx[(size_t)i * 3 + k] = it->second;
+            }
+        }
+        if (fits) {
+            trix.resize((size_t)sc->n_tris * 4);
+            for (int32_t i = 0; i < sc->n_tris; ++i) {
+                for (int k = 0; k < 3; ++k) trix[(size_t)i * 4 + k] = (uint16_t)idx[(size_t)i * 3 + k];
+                trix[(size_t)i * 4 + 3] = (uint16_t)sc->tris[i].mat;
+            }
+        } else { uverts.clear(); }
+    }
     SQ_HIP(hipSetDevice(device));
     sq_device_scene* s = new sq_device_scene;
     s->device = device; s->height = height;
@@ -504,7 +568,8 @@ extern "C" int sq_scene_upload(const sq_scene* sc, int32_t device, sq_device_sce
         return 0;
     };
     if (up(&s->d_branches, br.data(), br.size() * sizeof(DevBranch)) || up(&s->d_leaves, lf.data(), lf.size() * sizeof(DevLeaf)) ||
-        up(&s->d_tris, tr.data(), tr.size() * sizeof(DevTri)) || up(&s->d_mats, mt.data(), mt.size() * sizeof(DevMat))) {
+        up(&s->d_tris, tr.data(), tr.size() * sizeof(DevTri)) || up(&s->d_mats, mt.data(), mt.size() * sizeof(DevMat)) ||
+        up(&s->d_verts, uverts.data(), uverts.size() * sizeof(float)) || up(&s->d_trix, trix.data(), trix.size() * sizeof(uint16_t))) {
         sq_scene_free(s);
         return 1;
     }
@@ -515,6 +580,7 @@ extern "C" int sq_scene_upload(const sq_scene* sc, int32_t device, sq_device_sce
     v.root_ref = ref[0];
     v.n_branches = nb; v.n_leaves = nl; v.n_tris = sc->n_tris; v.n_mats = sc->n_mats;
     v.height = height; v.nonneg_materials = nonneg ? 1 : 0;
+    v.verts = (const float*)s->d_verts; v.trix = trix.empty() ? nullptr : (const ushort4*)s->d_trix; v.n_verts = (int32_t)(uverts.size() / 3);
     *out = s;
     return 0;
 }
@@ -523,7 +589,7 @@ extern "C" void sq_scene_free(sq_device_scene* s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
     for (auto& p : s->pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
-    (void)hipFree(s->d_branches); (void)hipFree(s->d_leaves); (void)hipFree(s->d_tris); (void)hipFree(s->d_mats);
+    (void)hipFree(s->d_branches); (void)hipFree(s->d_leaves); (void)hipFree(s->d_tris); (void)hipFree(s->d_mats); (void)hipFree(s->d_verts); (void)hipFree(s->d_trix);
     (void)hipFree(s->d_work);
     delete s;
 }
@@ -554,18 +620,16 @@ int ensure_workspace(sq_device_scene* s, int64_t pixels, int64_t slots) {
     auto take = [&](size_t bytes) { size_t o = off; off += al(bytes); return o; };
     const size_t o_cnt = take(64 * sizeof(int32_t));
     const size_t o_pix = take(pixels * 4), o_t0 = take(pixels * 4), o_tri0 = take(pixels * 4), o_sum = take(pixels * 12);
-    const size_t o_rng = take(slots * 8), o_rad = take(slots * 12);
-    size_t o_org[2], o_dir[2], o_hit[2];
-    for (int i = 0; i < 2; ++i) { o_org[i] = take(slots * 16); o_dir[i] = take(slots * 16); o_hit[i] = take(slots * 8); }
+    const size_t o_org = take(slots * 16), o_dir = take(slots * 16), o_hit = take(slots * 8), o_rng = take(slots * 8), o_rad = take(slots * 12);
     if (s->d_work) { (void)hipFree(s->d_work); s->d_work = nullptr; }
     if (hipMalloc(&s->d_work, off) != hipSuccess) return sq_set_error("hipMalloc(%zu B) for the frame workspace failed", off);
     char* base = (char*)s->d_work;
     Work& W = s->work;
     int32_t* cnt = (int32_t*)(base + o_cnt);
-    W.n_active = cnt; W.q_count[0] = cnt + 16; W.q_count[1] = cnt + 17; W.q_head[0] = cnt + 32; W.q_head[1] = cnt + 33;
+    W.n_active = cnt; W.head[0] = cnt + 16; W.head[1] = cnt + 32;      // separate cache lines
     W.px_pixel = (int32_t*)(base + o_pix); W.px_t0 = (float*)(base + o_t0); W.px_tri0 = (int32_t*)(base + o_tri0); W.px_sum = (float*)(base + o_sum);
+    W.org = (float4*)(base + o_org); W.dir = (float4*)(base + o_dir); W.hit = (int2*)(base + o_hit);
     W.rng12 = (uint2*)(base + o_rng); W.rad = (float*)(base + o_rad);
-    for (int i = 0; i < 2; ++i) { W.q_org[i] = (float4*)(base + o_org[i]); W.q_dir[i] = (float4*)(base + o_dir[i]); W.q_hit[i] = (int2*)(base + o_hit[i]); }
     W.slot_capacity = slots;
     s->work_bytes = off; s->work_pixels = pixels; s->work_slots = slots;
     return 0;
@@ -603,29 +667,47 @@ int launch_frame(sq_device_scene* s, const Frame& F, hipStream_t stream) {
     if (px_lds > 64 * 1024) SQ_HIP(hipFuncSetAttribute((const void*)sq_primary<StackT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)px_lds));
     hipLaunchKernelGGL(sq_primary<StackT>, dim3((unsigned)px_blocks), dim3(kBlock), px_lds, stream, S, F, W);
     SQ_HIP(hipGetLastError());
-    // persistent trace kernel geometry: LDS = staged branches + stacks
-    const size_t stack_bytes = (size_t)kTraceBlock * stack_cap * sizeof(StackT);
+    // persistent trace kernel geometry.  Resident form: the whole scene (branches, leaves, unique vertices,
+    // 16-bit indexed triangles) plus every lane's stack fits in the 160 KB of one CU -> one 1024-thread
+    // workgroup per CU, no global traffic except ray fetch and hit store.  Streaming form otherwise.
     const size_t lds_budget = 160 * 1024;
-    int n_lds = S.n_branches;
-    const size_t max_node_bytes = 64 * 1024;                               // leave room for >= 2 workgroups per CU
-    if ((size_t)n_lds * 48 > max_node_bytes) n_lds = (int)(max_node_bytes / 48);
-    const size_t tr_lds = (((size_t)n_lds * 48 + 15) & ~(size_t)15) + stack_bytes;
-    if (tr_lds > lds_budget) return sq_set_error("BIH height %d needs %zu B of LDS per workgroup (max %zu)", S.height, tr_lds, lds_budget);
-    if (tr_lds > 64 * 1024) SQ_HIP(hipFuncSetAttribute((const void*)sq_trace_rays<StackT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tr_lds));
-    int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, lds_budget / tr_lds));
-    if (s->opt_trace_blocks_per_cu > 0) per_cu = (int)s->opt_trace_blocks_per_cu;
-    const int trace_blocks = s->n_cu * per_cu;
+    bool resident = false;
+    TraceLds L{};
+    if (s->opt_resident && S.trix) {
+        L = trace_lds_layout(S.n_branches, true, S.n_leaves, S.n_verts, S.n_tris, kResidentBlock, stack_cap, (int)sizeof(StackT));
+        resident = L.total <= lds_budget;
+    }
+    int n_lds = S.n_branches, trace_blocks = 0, trace_threads = 0;
+    const void* trace_fn = nullptr;
+    if (resident) {
+        trace_fn = (const void*)sq_trace_rays<StackT, true, kResidentBlock>;
+        trace_blocks = s->n_cu; trace_threads = kResidentBlock;
+    } else {
+        const size_t max_node_bytes = 64 * 1024;                           // leave room for >= 2 workgroups per CU
+        if ((size_t)n_lds * 48 > max_node_bytes) n_lds = (int)(max_node_bytes / 48);
+        L = trace_lds_layout(n_lds, false, S.n_leaves, S.n_verts, S.n_tris, kTraceBlock, stack_cap, (int)sizeof(StackT));
+        if (L.total > lds_budget) return sq_set_error("BIH height %d needs %u B of LDS per workgroup (max %zu)", S.height, L.total, lds_budget);
+        trace_fn = (const void*)sq_trace_rays<StackT, false, kTraceBlock>;
+        int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, lds_budget / L.total));
+        if (s->opt_trace_blocks_per_cu > 0) per_cu = (int)s->opt_trace_blocks_per_cu;
+        trace_blocks = s->n_cu * per_cu; trace_threads = kTraceBlock;
+    }
+    const size_t tr_lds = L.total;
+    if (tr_lds > 64 * 1024) SQ_HIP(hipFuncSetAttribute(trace_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tr_lds));
     const int aux_blocks = s->n_cu * 8;
     for (int k0 = 0; k0 < F.samples; k0 += batch) {
         const int kc = std::min(batch, F.samples - k0);
-        SQ_HIP(hipMemsetAsync(W.q_count[0], 0, 32 * sizeof(int32_t), stream));   // both queue counters and both cursors
+        SQ_HIP(hipMemsetAsync(W.head[0], 0, 32 * sizeof(int32_t), stream));     // both dequeue cursors
         hipLaunchKernelGGL(sq_gen_bounce1, dim3(aux_blocks), dim3(kBlock), 0, stream, S, F, W, k0, kc);
         SQ_HIP(hipGetLastError());
         for (int level = 0; level < 2; ++level) {
-            TraceArgs A{ W.q_org[level], W.q_dir[level], W.q_hit[level], W.q_count[level], W.q_head[level], n_lds, stack_cap, (int32_t)s->opt_straggler };
-            if (timed([&] { hipLaunchKernelGGL(sq_trace_rays<StackT>, dim3(trace_blocks), dim3(kTraceBlock), tr_lds, stream, S, A); }, "sq_trace_rays")) return 1;
-            if (level == 0) hipLaunchKernelGGL(sq_shade1, dim3(aux_blocks), dim3(kBlock), 0, stream, S, F, W);
-            else hipLaunchKernelGGL(sq_shade2, dim3(aux_blocks), dim3(kBlock), 0, stream, S, F, W);
+            TraceArgs A{ W.org, W.dir, W.hit, W.n_active, kc, W.head[level], n_lds, stack_cap, (int32_t)s->opt_straggler };
+            if (timed([&] {
+                    if (resident) hipLaunchKernelGGL((sq_trace_rays<StackT, true, kResidentBlock>), dim3(trace_blocks), dim3(trace_threads), tr_lds, stream, S, A);
+                    else hipLaunchKernelGGL((sq_trace_rays<StackT, false, kTraceBlock>), dim3(trace_blocks), dim3(trace_threads), tr_lds, stream, S, A);
+                }, "sq_trace_rays")) return 1;
+            if (level == 0) hipLaunchKernelGGL(sq_shade1, dim3(aux_blocks), dim3(kBlock), 0, stream, S, F, W, kc);
+            else hipLaunchKernelGGL(sq_shade2, dim3(aux_blocks), dim3(kBlock), 0, stream, S, F, W, kc);
             SQ_HIP(hipGetLastError());
         }
         hipLaunchKernelGGL(sq_accumulate, dim3(aux_blocks), dim3(kBlock), 0, stream, F, W, kc, (k0 + kc >= F.samples) ? 1 : 0);
@@ -680,8 +762,9 @@ extern "C" int sq_set_option(sq_device_scene* s, const char* key, int64_t value)
     if (!s || !key) return sq_set_error("null argument");
     if (!std::strcmp(key, "timing")) { s->opt_timing = value; return 0; }
     if (!std::strcmp(key, "variant")) { if (value != 1 && value != 2) return sq_set_error("variant must be 1 (per-pixel kernel) or 2 (wavefront)"); s->opt_variant = value; return 0; }
-    if (!std::strcmp(key, "slots")) { if (value < 1) return sq_set_error("slots must be positive"); s->opt_slots = value; return 0; }
+    if (!std::strcmp(key, "slots")) { if (value < 1 || value > (512ll << 20)) return sq_set_error("slots must be in 1..2^29"); s->opt_slots = value; return 0; }
     if (!std::strcmp(key, "straggler_lanes")) { if (value < 0 || value > 63) return sq_set_error("straggler_lanes must be in 0..63"); s->opt_straggler = value; return 0; }
+    if (!std::strcmp(key, "resident")) { s->opt_resident = value ? 1 : 0; return 0; }
     if (!std::strcmp(key, "trace_blocks_per_cu")) { if (value < 0 || value > 8) return sq_set_error("trace_blocks_per_cu must be in 0..8"); s->opt_trace_blocks_per_cu = value; return 0; }
     return sq_set_error("unknown option '%s'", key);
 }

@@ -11,6 +11,14 @@ using sq::f3;
 
 constexpr uint32_t kLeafBit = 0x80000000u;   // child reference: leaf index | kLeafBit, or branch index
 
+// Builtin vector types and explicit LDS (address space 3) pointers: a load through an LDS-qualified
+// pointer is always a ds_read, never a flat load, and cannot be merged with a global pointer.
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef int v2i __attribute__((ext_vector_type(2)));
+typedef unsigned short v4us __attribute__((ext_vector_type(4)));
+#define SQ_LDS __attribute__((address_space(3)))
+template <typename T> __device__ __forceinline__ SQ_LDS T* to_lds(void* generic) { return (SQ_LDS T*)generic; }
+
 // HBM layout (read-only during a render).  Branches are numbered breadth-first so that the top
 // of the tree is a prefix of the table (that prefix is what gets staged in LDS).
 struct DevBranch {          // 48 B, three 16-byte quads
@@ -34,6 +42,9 @@ struct SceneView {
     float root_lo[3], root_hi[3];
     uint32_t root_ref;
     int32_t n_branches, n_leaves, n_tris, n_mats;
+    const float* verts;       // unique vertices, 3 floats each (indexed form of the triangles, for LDS residency)
+    const ushort4* trix;      // per triangle: vertex indices i0,i1,i2 and material; nullptr if indices exceed 16 bits
+    int32_t n_verts;
     int32_t height;           // BIH.height; a traversal never holds more than height-1 frames
     int32_t nonneg_materials; // 1 if every material component is >= +0 (enables the exact s == 0 shortcuts)
 };
@@ -146,13 +157,43 @@ template <typename StackT> struct StackTraits;
 template <> struct StackTraits<uint16_t> { static constexpr uint32_t flag = 0x8000u; };
 template <> struct StackTraits<uint32_t> { static constexpr uint32_t flag = 0x80000000u; };
 
-struct GlobalNodes {
+struct GlobalNodes {            // every branch read from HBM/L2
     const float4* g;
-    __device__ __forceinline__ float4 quad(uint32_t b, int k) const { return g[3 * b + k]; }
+    __device__ __forceinline__ v4f quad(uint32_t b, int k) const { const float4 q = g[3 * b + k]; return v4f{ q.x, q.y, q.z, q.w }; }
 };
-struct LdsNodes {               // first n_lds branches staged in LDS, the rest read from HBM/L2
-    const float4* l; const float4* g; uint32_t n_lds;
-    __device__ __forceinline__ float4 quad(uint32_t b, int k) const { return b < n_lds ? l[3 * b + k] : g[3 * b + k]; }
+struct LdsNodes {               // every branch staged in LDS (resident form)
+    const SQ_LDS v4f* l;
+    __device__ __forceinline__ v4f quad(uint32_t b, int k) const { return l[3 * b + k]; }
+};
+struct HybridNodes {            // first n_lds branches (top of the tree) in LDS, the rest from HBM/L2
+    const SQ_LDS v4f* l; const float4* g; uint32_t n_lds;
+    __device__ __forceinline__ v4f quad(uint32_t b, int k) const {
+        if (b < n_lds) return l[3 * b + k];
+        const float4 q = g[3 * b + k];
+        return v4f{ q.x, q.y, q.z, q.w };
+    }
+};
+
+// Triangle sources: (v0, e1, e2) of triangle i.  e1 = v1 - v0 and e2 = v2 - v0 are the reference's
+// edge1/edge2 (src/Geometry.hs:130-131) whether they were subtracted at upload or here.
+struct GlobalTris {
+    const float4* t; const int2* leaves;
+    __device__ __forceinline__ void get(int i, f3& v0, f3& e1, f3& e2) const {
+        const float4 a = t[3 * i], b = t[3 * i + 1], c = t[3 * i + 2];
+        v0 = sq::mk(a.x, a.y, a.z); e1 = sq::mk(b.x, b.y, b.z); e2 = sq::mk(c.x, c.y, c.z);
+    }
+    __device__ __forceinline__ int2 leaf(uint32_t k) const { return leaves[k]; }
+};
+struct LdsTris {                // whole scene resident in LDS: indexed triangles + unique vertices
+    const SQ_LDS float* verts; const SQ_LDS v4us* trix; const SQ_LDS v2i* leaves;
+    __device__ __forceinline__ void get(int i, f3& v0, f3& e1, f3& e2) const {
+        const v4us r = trix[i];
+        const SQ_LDS float* p0 = verts + 3 * r.x; const SQ_LDS float* p1 = verts + 3 * r.y; const SQ_LDS float* p2 = verts + 3 * r.z;
+        v0 = sq::mk(p0[0], p0[1], p0[2]);
+        e1 = sq::mk(p1[0], p1[1], p1[2]) - v0;
+        e2 = sq::mk(p2[0], p2[1], p2[2]) - v0;
+    }
+    __device__ __forceinline__ int2 leaf(uint32_t k) const { const v2i l = leaves[k]; return make_int2(l.x, l.y); }
 };
 
 struct Trav {
@@ -174,8 +215,8 @@ __device__ __forceinline__ void trav_begin(Trav& T, const SceneView& S, f3 o, f3
 
 // One Branch equation (src/BIH.hs:111-141).  Pre: mode == M_DESCEND.
 template <typename NodeSrc, typename StackT>
-__device__ __forceinline__ void trav_descend(Trav& T, const NodeSrc& N, StackT* stk, int stride) {
-    const float4 q0 = N.quad(T.cur, 0), q1 = N.quad(T.cur, 1), q2 = N.quad(T.cur, 2);
+__device__ __forceinline__ void trav_descend(Trav& T, const NodeSrc& N, SQ_LDS StackT* stk, int stride) {
+    const v4f q0 = N.quad(T.cur, 0), q1 = N.quad(T.cur, 1), q2 = N.quad(T.cur, 2);
     const int ax = __float_as_int(q2.x);
     const uint32_t left = __float_as_uint(q2.y), right = __float_as_uint(q2.z);
     const float lmax = q0.w, rmin = q1.w;
@@ -193,37 +234,41 @@ __device__ __forceinline__ void trav_descend(Trav& T, const NodeSrc& N, StackT* 
 }
 
 // One triangle of a Leaf equation folded into R with minimumBy's rule (src/BIH.hs:105-109).
-__device__ __forceinline__ void leaf_fold(Trav& T, const SceneView& S, int i) {
-    const float4 a = S.tris[3 * i], b = S.tris[3 * i + 1], c = S.tris[3 * i + 2];
+template <typename TriSrc>
+__device__ __forceinline__ void leaf_fold(Trav& T, const TriSrc& G, int i) {
+    f3 v0, e1, e2;
+    G.get(i, v0, e1, e2);
     float t, dist;
-    if (moller_trumbore(T.o, T.d, sq::mk(a.x, a.y, a.z), sq::mk(b.x, b.y, b.z), sq::mk(c.x, c.y, c.z), t, dist)) {
+    if (moller_trumbore(T.o, T.d, v0, e1, e2, t, dist)) {
         if (T.R.tri < 0 || sq::cmp_gt(T.R.dist, dist)) { T.R.t = t; T.R.dist = dist; T.R.tri = i; }   // replace only on GT
     }
 }
 // The whole Leaf equation.  Pre: mode == M_LEAF.
-__device__ __forceinline__ void trav_leaf(Trav& T, const SceneView& S) {
-    const int2 lf = S.leaves[T.cur & ~kLeafBit];
+template <typename TriSrc>
+__device__ __forceinline__ void trav_leaf(Trav& T, const TriSrc& G) {
+    const int2 lf = G.leaf(T.cur & ~kLeafBit);
     T.R.tri = -1;
-    for (int i = lf.x; i < lf.x + lf.y; ++i) leaf_fold(T, S, i);
+    for (int i = lf.x; i < lf.x + lf.y; ++i) leaf_fold(T, G, i);
     T.mode = M_UNWIND;
 }
 
 // Return to the caller of the call that just produced R: pop one frame.  Pre: mode == M_UNWIND.
-template <typename NodeSrc, typename StackT>
-__device__ __forceinline__ void trav_unwind(Trav& T, const SceneView& S, const NodeSrc& N, StackT* stk, int stride) {
+template <typename NodeSrc, typename TriSrc, typename StackT>
+__device__ __forceinline__ void trav_unwind(Trav& T, const NodeSrc& N, const TriSrc& G, SQ_LDS StackT* stk, int stride) {
     constexpr uint32_t flag = StackTraits<StackT>::flag;
     if (T.sp == 0) { T.mode = M_DONE; return; }
     --T.sp;
     const uint32_t e = stk[T.sp * stride];
     if (e & flag) {                                                     // minimumByMay over [near, far] (src/BIH.hs:115,120)
         const int32_t ntri = (int32_t)(e & ~flag);
-        const float4 a = S.tris[3 * ntri], b = S.tris[3 * ntri + 1], c = S.tris[3 * ntri + 2];
+        f3 v0, e1, e2;
+        G.get(ntri, v0, e1, e2);
         float nt = 0, ndist = 0;
-        (void)moller_trumbore(T.o, T.d, sq::mk(a.x, a.y, a.z), sq::mk(b.x, b.y, b.z), sq::mk(c.x, c.y, c.z), nt, ndist);
+        (void)moller_trumbore(T.o, T.d, v0, e1, e2, nt, ndist);
         if (T.R.tri < 0 || !sq::cmp_gt(ndist, T.R.dist)) { T.R.t = nt; T.R.dist = ndist; T.R.tri = ntri; }   // ties keep near
         return;
     }
-    const float4 q0 = N.quad(e, 0), q1 = N.quad(e, 1), q2 = N.quad(e, 2);  // back in branch e: its near child returned R
+    const v4f q0 = N.quad(e, 0), q1 = N.quad(e, 1), q2 = N.quad(e, 2);     // back in branch e: its near child returned R
     const int ax = __float_as_int(q2.x);
     const bool l2r = sq::axis_of(T.d, ax) > 0;
     if (T.R.tri >= 0) {
@@ -238,13 +283,14 @@ __device__ __forceinline__ void trav_unwind(Trav& T, const SceneView& S, const N
 
 // Whole query, one ray per lane (used where rays of a wave are coherent: primary and shadow rays).
 template <typename NodeSrc, typename StackT>
-__device__ __forceinline__ Hit trace_one(const SceneView& S, const NodeSrc& N, f3 o, f3 d, StackT* stk, int stride) {
+__device__ __forceinline__ Hit trace_one(const SceneView& S, const NodeSrc& N, f3 o, f3 d, SQ_LDS StackT* stk, int stride) {
+    const GlobalTris G{ S.tris, S.leaves };
     Trav T;
     trav_begin<NodeSrc>(T, S, o, d);
     while (T.mode != M_DONE) {
         while (T.mode == M_DESCEND) trav_descend(T, N, stk, stride);
-        if (T.mode == M_LEAF) trav_leaf(T, S);
-        while (T.mode == M_UNWIND) trav_unwind(T, S, N, stk, stride);
+        if (T.mode == M_LEAF) trav_leaf(T, G);
+        while (T.mode == M_UNWIND) trav_unwind(T, N, G, stk, stride);
     }
     return T.R;
 }

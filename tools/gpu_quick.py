@@ -36,11 +36,22 @@ for variant in (1, 2):
         t = time.time(); ds.render_rows(cam, n, w, h); torch.cuda.synchronize(); dt = time.time() - t
         ms, cnt, name = ds.kernel_timing()
         print(f"variant {variant} {w}x{h}@{n}: wall {dt*1e3:.1f} ms -> {w*h*n/dt/1e6:.1f} Msamples/s   [{name}: {cnt} launches, {ms*cnt:.1f} ms total]", flush=True)
+for res in (0, 1):
+    ds.set_option("variant", 2); ds.set_option("resident", res)
+    a, r = ds.render_rows(cam, 16, 96, 96); torch.cuda.synchronize()
+    o_avg, o_rgb, _ = ob.render(oc, 16, 96, 96, threads=16)
+    same = np.array_equal(a.cpu().numpy().view(np.uint32), o_avg.view(np.uint32))
+    ok &= same
+    for (w, h, n) in [(540, 540, 64), (1920, 1080, 64)]:
+        ds.render_rows(cam, n, w, h); torch.cuda.synchronize(); ds.reset_timing()
+        t = time.time(); ds.render_rows(cam, n, w, h); torch.cuda.synchronize(); dt = time.time() - t
+        ms, cnt, name = ds.kernel_timing()
+        print(f"resident={res} parity={same} {w}x{h}@{n}: {w*h*n/dt/1e6:.1f} Msamples/s (trace {ms*cnt:.1f} ms of {dt*1e3:.1f})", flush=True)
 if "sweep" in args:
     ds.set_option("variant", 2)
     w, h, n = 1920, 1080, 64
-    for strag in (0, 4, 8, 12, 16, 24, 32, 48):
-        for bpc in (1, 2, 3, 4):
+    for strag in (0, 2, 4, 6, 8, 12, 16):
+        for bpc in (0,):
             ds.set_option("straggler_lanes", strag); ds.set_option("trace_blocks_per_cu", bpc)
             ds.render_rows(cam, n, w, h); torch.cuda.synchronize(); ds.reset_timing()
             t = time.time(); ds.render_rows(cam, n, w, h); torch.cuda.synchronize(); dt = time.time() - t

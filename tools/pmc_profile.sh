@@ -14,19 +14,19 @@ for CTRS in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST
             "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" \
             "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  timeout -k 10 300 rocprofv3 --pmc $CTRS --kernel-include-regex sq_render --output-format csv -d $OUT/pass$i -- python bench.py --no-cpu "$@" > $OUT/pass$i.log 2>&1
+  timeout -k 10 300 rocprofv3 --pmc $CTRS --kernel-include-regex "sq_" --output-format csv -d $OUT/pass$i -- python bench.py --no-cpu "$@" > $OUT/pass$i.log 2>&1
   echo "pass $i ($CTRS) rc=$?"
 done
 python - <<PY
 import csv, glob, collections
 tot = collections.OrderedDict()
-n = 0
 for f in sorted(glob.glob("$OUT/pass*/*/*counter_collection.csv")):
     for r in csv.DictReader(open(f)):
-        if "sq_render" not in r["Kernel_Name"]: continue
-        tot.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+        kn = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        if not kn.startswith("sq_"): continue
+        tot.setdefault((kn, r["Counter_Name"]), []).append(float(r["Counter_Value"]))
 with open("$OUT/summary.txt", "w") as o:
-    for k, v in tot.items():
-        line = f"{k:32s} launches={len(v)} mean_per_launch={sum(v)/len(v):.6g}"
+    for (kn, k), v in tot.items():
+        line = f"{kn:34s} {k:30s} launches={len(v):3d} sum={sum(v):.6g} mean_per_launch={sum(v)/len(v):.6g}"
         print(line); o.write(line + "\n")
 PY
