@@ -80,6 +80,9 @@ int sq_render_rows_device(sq_device_scene* s, const sq_camera* cam, int32_t samp
  * average duration in ms over the launches since the last reset, and the launch count. */
 int  sq_kernel_timing(sq_device_scene* s, double* avg_ms, int64_t* launches, const char** kernel_name);
 void sq_kernel_timing_reset(sq_device_scene* s);
+/* Cumulative statistics of the trace kernel since the last reset (synchronises the device):
+ * out[0] = rays traced; out[1..8] = lane-occupancy counters, filled only with option "profile" = 1. */
+int  sq_get_stats(sq_device_scene* s, uint64_t* out, int32_t n, int32_t reset);
 /* Tunables (0 = library default). variant selects a kernel implementation; all produce identical bits. */
 int  sq_set_option(sq_device_scene* s, const char* key, int64_t value);
 

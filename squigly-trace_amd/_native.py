@@ -70,6 +70,7 @@ def lib():
     L.sq_kernel_timing_reset.argtypes = [vp]
     L.sq_kernel_timing_reset.restype = None
     L.sq_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
+    L.sq_get_stats.argtypes = [vp, C.POINTER(C.c_uint64), i32, i32]
     L.sq_debug_eval.argtypes = [i32, i32, vp, vp, C.c_int64, vp]
     # host side
     L.sq_mesh_from_obj.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(vp)]
@@ -128,7 +129,7 @@ EXPORTED_SYMBOLS = [
     # include/squigly_hip.h
     "sq_render_rgb8", "sq_render_f32", "sq_scene_upload", "sq_scene_free", "sq_shard_rows",
     "sq_shard_global_row", "sq_render_rows_device", "sq_kernel_timing", "sq_kernel_timing_reset",
-    "sq_set_option", "sq_debug_eval", "sq_device_count", "sq_abi_version", "sq_last_error",
+    "sq_set_option", "sq_get_stats", "sq_debug_eval", "sq_device_count", "sq_abi_version", "sq_last_error",
     # include/squigly_host.h
     "sq_mesh_from_obj", "sq_mesh_from_text", "sq_mesh_from_arrays", "sq_mesh_num_tris",
     "sq_mesh_num_materials", "sq_mesh_tris", "sq_mesh_materials", "sq_mesh_free", "sq_camera_from_file",

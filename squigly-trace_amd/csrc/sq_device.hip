@@ -129,6 +129,7 @@ struct Work {                 // device workspace of one frame (HBM)
     uint2*   rng12;           // (n1, n2) of the sample's generator
     float*   rad;             // finished sample radiance, 3 floats
     int32_t* head[2];         // dequeue cursors of the persistent trace kernel, one per bounce level
+    unsigned long long* stats;  // cumulative trace-kernel statistics (TraceArgs::stats)
     int64_t  slot_capacity;
 };
 constexpr float kLive = 1.0f, kDead = -1.0f;
@@ -281,6 +282,9 @@ struct TraceArgs {
     const float4* org; const float4* dir; int2* hits;
     const int32_t* n_active; int32_t k_count; int32_t* head;
     int32_t n_lds; int32_t stack_cap; int32_t straggler_lanes;
+    unsigned long long* stats;   // [0] rays traced; PROFILE builds: [1] advance iterations (waves), [2] lanes unwinding,
+                                 // [3] lanes descending, [4] leaf iterations (waves), [5] lanes testing a triangle,
+                                 // [6] outer iterations (waves), [7] refill executions (waves), [8] lanes refilled
 };
 // LDS carve-up of the trace kernel (bytes, all 16-B aligned), shared by host and device.
 struct TraceLds { uint32_t nodes, leaves, verts, trix, live, stack, total; };
@@ -298,7 +302,12 @@ __host__ __device__ inline TraceLds trace_lds_layout(int n_lds, bool resident, i
     return L;
 }
 
-template <typename StackT, bool RESIDENT, int BLOCK>
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+    return v;
+}
+template <typename StackT, bool RESIDENT, int BLOCK, bool PROFILE>
 __global__ void __launch_bounds__(BLOCK) sq_trace_rays(const SceneView S, const TraceArgs A) {
     extern __shared__ float4 lds_raw[];
     char* lds = reinterpret_cast<char*>(lds_raw);
@@ -333,41 +342,51 @@ __global__ void __launch_bounds__(BLOCK) sq_trace_rays(const SceneView S, const 
     int list_pos = 0, list_len = 0;         // wave-uniform
     bool exhausted = false;                 // wave-uniform
     long long my_ray = -1;
+    unsigned long long n_traced = 0;        // wave-uniform
+    unsigned long long pf_adv = 0, pf_leaf = 0, pf_outer = 0, pf_refill = 0;   // wave-uniform (PROFILE)
+    unsigned int pl_unw = 0, pl_desc = 0, pl_tri = 0, pl_ref = 0;               // per lane (PROFILE)
     Trav T; T.mode = M_DONE; T.sp = 0; T.cur = 0; T.R.tri = -1; T.R.t = 0; T.R.dist = 0;
     T.o = T.d = T.df = sq::mk(0, 0, 0);
+    auto refill = [&](unsigned long long m, bool idle) {             // m = ballot(idle), wave-uniform
+        while (!exhausted && list_pos == list_len) {                    // reserve and compact the next chunk
+            int base = 0;
+            if (lane == 0) base = atomicAdd(A.head, kChunk);
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (base >= n) { exhausted = true; break; }
+            chunk_base = base; list_pos = 0; list_len = 0;
+#pragma unroll
+            for (int j = 0; j < kChunk / 64; ++j) {
+                const long long idx = chunk_base + j * 64 + lane;
+                const bool alive = idx < n && A.org[idx].w >= 0.0f;
+                const unsigned long long am = __ballot(alive);
+                if (alive) live[list_len + __popcll(am & lt_mask)] = (uint16_t)(j * 64 + lane);
+                list_len += __popcll(am);
+            }
+            n_traced += (unsigned long long)list_len;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        if (exhausted) return;
+        const int rank = __popcll(m & lt_mask);
+        const int avail = list_len - list_pos;
+        if (PROFILE) ++pf_refill;
+        if (idle && rank < avail) {
+            if (PROFILE) ++pl_ref;
+            my_ray = chunk_base + live[list_pos + rank];
+            const float4 o = A.org[my_ray], d = A.dir[my_ray];
+            trav_begin<NodeSrc>(T, S, sq::mk(o.x, o.y, o.z), sq::mk(d.x, d.y, d.z));
+        }
+        list_pos += min(__popcll(m), avail);
+    };
     for (;;) {
+        if (PROFILE) ++pf_outer;
         const bool idle = (T.mode == M_DONE);
         if (idle && my_ray >= 0) { A.hits[my_ray] = make_int2(__float_as_int(T.R.t), T.R.tri); my_ray = -1; }
         const unsigned long long m = __ballot(idle);
         if (m) {
-            while (!exhausted && list_pos == list_len) {                        // reserve and compact the next chunk
-                int base = 0;
-                if (lane == 0) base = atomicAdd(A.head, kChunk);
-                base = __builtin_amdgcn_readfirstlane(base);
-                if (base >= n) { exhausted = true; break; }
-                chunk_base = base; list_pos = 0; list_len = 0;
-#pragma unroll
-                for (int j = 0; j < kChunk / 64; ++j) {
-                    const long long idx = chunk_base + j * 64 + lane;
-                    const bool alive = idx < n && A.org[idx].w >= 0.0f;
-                    const unsigned long long am = __ballot(alive);
-                    if (alive) live[list_len + __popcll(am & lt_mask)] = (uint16_t)(j * 64 + lane);
-                    list_len += __popcll(am);
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            }
-            if (!exhausted) {
-                const int rank = __popcll(m & lt_mask);
-                const int avail = list_len - list_pos;
-                if (idle && rank < avail) {
-                    my_ray = chunk_base + live[list_pos + rank];
-                    const float4 o = A.org[my_ray], d = A.dir[my_ray];
-                    trav_begin<NodeSrc>(T, S, sq::mk(o.x, o.y, o.z), sq::mk(d.x, d.y, d.z));
-                }
-                list_pos += min(__popcll(m), avail);
-            } else if (m == ~0ull) break;
+            refill(m, idle);
+            if (exhausted && m == ~0ull) break;
         }
         // advance until (almost) every lane has a leaf to test or is finished
         for (;;) {
@@ -375,10 +394,22 @@ __global__ void __launch_bounds__(BLOCK) sq_trace_rays(const SceneView S, const 
             const unsigned long long am = __ballot(adv);
             if (am == 0) break;
             if (__popcll(am) <= A.straggler_lanes && __ballot(T.mode == M_LEAF) != 0) break;
+            if (PROFILE) { ++pf_adv; pl_unw += (T.mode == M_UNWIND); }
             if (T.mode == M_UNWIND) trav_unwind(T, N, G, stk, BLOCK);
+            if (PROFILE) pl_desc += (T.mode == M_DESCEND);
             if (T.mode == M_DESCEND) trav_descend(T, N, stk, BLOCK);
         }
+        if (PROFILE) {
+            const int cnt = (T.mode == M_LEAF) ? G.leaf(T.cur & ~kLeafBit).y : 0;
+            pl_tri += cnt; pf_leaf += wave_max(cnt);
+        }
         if (T.mode == M_LEAF) trav_leaf(T, G);
+    }
+    if (lane == 0) atomicAdd(&A.stats[0], n_traced);
+    if (PROFILE) {
+        if (lane == 0) { atomicAdd(&A.stats[1], pf_adv); atomicAdd(&A.stats[4], pf_leaf); atomicAdd(&A.stats[6], pf_outer); atomicAdd(&A.stats[7], pf_refill); }
+        atomicAdd(&A.stats[2], (unsigned long long)pl_unw); atomicAdd(&A.stats[3], (unsigned long long)pl_desc);
+        atomicAdd(&A.stats[5], (unsigned long long)pl_tri); atomicAdd(&A.stats[8], (unsigned long long)pl_ref);
     }
 }
 
@@ -418,7 +449,7 @@ struct sq_device_scene {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
     double total_ms = 0; int64_t launches = 0;
     // options
-    int64_t opt_timing = 1, opt_variant = 2, opt_slots = 48ll << 20, opt_straggler = 6, opt_trace_blocks_per_cu = 0, opt_resident = 1;
+    int64_t opt_timing = 1, opt_variant = 2, opt_slots = 48ll << 20, opt_straggler = 6, opt_trace_blocks_per_cu = 0, opt_resident = 1, opt_profile = 0;
     const char* last_kernel = "sq_trace_rays";
 };
 
@@ -619,6 +650,7 @@ int ensure_workspace(sq_device_scene* s, int64_t pixels, int64_t slots) {
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += al(bytes); return o; };
     const size_t o_cnt = take(64 * sizeof(int32_t));
+    const size_t o_stats = take(16 * sizeof(unsigned long long));
     const size_t o_pix = take(pixels * 4), o_t0 = take(pixels * 4), o_tri0 = take(pixels * 4), o_sum = take(pixels * 12);
     const size_t o_org = take(slots * 16), o_dir = take(slots * 16), o_hit = take(slots * 8), o_rng = take(slots * 8), o_rad = take(slots * 12);
     if (s->d_work) { (void)hipFree(s->d_work); s->d_work = nullptr; }
@@ -627,6 +659,8 @@ int ensure_workspace(sq_device_scene* s, int64_t pixels, int64_t slots) {
     Work& W = s->work;
     int32_t* cnt = (int32_t*)(base + o_cnt);
     W.n_active = cnt; W.head[0] = cnt + 16; W.head[1] = cnt + 32;      // separate cache lines
+    W.stats = (unsigned long long*)(base + o_stats);
+    if (hipMemset(W.stats, 0, 16 * sizeof(unsigned long long)) != hipSuccess) return sq_set_error("hipMemset failed");
     W.px_pixel = (int32_t*)(base + o_pix); W.px_t0 = (float*)(base + o_t0); W.px_tri0 = (int32_t*)(base + o_tri0); W.px_sum = (float*)(base + o_sum);
     W.org = (float4*)(base + o_org); W.dir = (float4*)(base + o_dir); W.hit = (int2*)(base + o_hit);
     W.rng12 = (uint2*)(base + o_rng); W.rad = (float*)(base + o_rad);
@@ -680,14 +714,14 @@ int launch_frame(sq_device_scene* s, const Frame& F, hipStream_t stream) {
     int n_lds = S.n_branches, trace_blocks = 0, trace_threads = 0;
     const void* trace_fn = nullptr;
     if (resident) {
-        trace_fn = (const void*)sq_trace_rays<StackT, true, kResidentBlock>;
+        trace_fn = s->opt_profile ? (const void*)sq_trace_rays<StackT, true, kResidentBlock, true> : (const void*)sq_trace_rays<StackT, true, kResidentBlock, false>;
         trace_blocks = s->n_cu; trace_threads = kResidentBlock;
     } else {
         const size_t max_node_bytes = 64 * 1024;                           // leave room for >= 2 workgroups per CU
         if ((size_t)n_lds * 48 > max_node_bytes) n_lds = (int)(max_node_bytes / 48);
         L = trace_lds_layout(n_lds, false, S.n_leaves, S.n_verts, S.n_tris, kTraceBlock, stack_cap, (int)sizeof(StackT));
         if (L.total > lds_budget) return sq_set_error("BIH height %d needs %u B of LDS per workgroup (max %zu)", S.height, L.total, lds_budget);
-        trace_fn = (const void*)sq_trace_rays<StackT, false, kTraceBlock>;
+        trace_fn = s->opt_profile ? (const void*)sq_trace_rays<StackT, false, kTraceBlock, true> : (const void*)sq_trace_rays<StackT, false, kTraceBlock, false>;
         int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, lds_budget / L.total));
         if (s->opt_trace_blocks_per_cu > 0) per_cu = (int)s->opt_trace_blocks_per_cu;
         trace_blocks = s->n_cu * per_cu; trace_threads = kTraceBlock;
@@ -701,10 +735,10 @@ int launch_frame(sq_device_scene* s, const Frame& F, hipStream_t stream) {
         hipLaunchKernelGGL(sq_gen_bounce1, dim3(aux_blocks), dim3(kBlock), 0, stream, S, F, W, k0, kc);
         SQ_HIP(hipGetLastError());
         for (int level = 0; level < 2; ++level) {
-            TraceArgs A{ W.org, W.dir, W.hit, W.n_active, kc, W.head[level], n_lds, stack_cap, (int32_t)s->opt_straggler };
+            TraceArgs A{ W.org, W.dir, W.hit, W.n_active, kc, W.head[level], n_lds, stack_cap, (int32_t)s->opt_straggler, W.stats };
             if (timed([&] {
-                    if (resident) hipLaunchKernelGGL((sq_trace_rays<StackT, true, kResidentBlock>), dim3(trace_blocks), dim3(trace_threads), tr_lds, stream, S, A);
-                    else hipLaunchKernelGGL((sq_trace_rays<StackT, false, kTraceBlock>), dim3(trace_blocks), dim3(trace_threads), tr_lds, stream, S, A);
+                    void* kargs[] = { (void*)&S, (void*)&A };
+                    (void)hipLaunchKernel(trace_fn, dim3(trace_blocks), dim3(trace_threads), kargs, tr_lds, stream);
                 }, "sq_trace_rays")) return 1;
             if (level == 0) hipLaunchKernelGGL(sq_shade1, dim3(aux_blocks), dim3(kBlock), 0, stream, S, F, W, kc);
             else hipLaunchKernelGGL(sq_shade2, dim3(aux_blocks), dim3(kBlock), 0, stream, S, F, W, kc);
@@ -758,6 +792,16 @@ extern "C" void sq_kernel_timing_reset(sq_device_scene* s) {
     for (auto& p : s->pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     s->pending.clear(); s->total_ms = 0; s->launches = 0;
 }
+extern "C" int sq_get_stats(sq_device_scene* s, uint64_t* out, int32_t n, int32_t reset) {
+    if (!s || !out || n < 0 || n > 16) return sq_set_error("bad argument");
+    for (int i = 0; i < n; ++i) out[i] = 0;
+    if (!s->d_work) return 0;
+    SQ_HIP(hipSetDevice(s->device));
+    SQ_HIP(hipDeviceSynchronize());
+    SQ_HIP(hipMemcpy(out, s->work.stats, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if (reset) SQ_HIP(hipMemset(s->work.stats, 0, 16 * sizeof(uint64_t)));
+    return 0;
+}
 extern "C" int sq_set_option(sq_device_scene* s, const char* key, int64_t value) {
     if (!s || !key) return sq_set_error("null argument");
     if (!std::strcmp(key, "timing")) { s->opt_timing = value; return 0; }
@@ -765,6 +809,7 @@ extern "C" int sq_set_option(sq_device_scene* s, const char* key, int64_t value)
     if (!std::strcmp(key, "slots")) { if (value < 1 || value > (512ll << 20)) return sq_set_error("slots must be in 1..2^29"); s->opt_slots = value; return 0; }
     if (!std::strcmp(key, "straggler_lanes")) { if (value < 0 || value > 63) return sq_set_error("straggler_lanes must be in 0..63"); s->opt_straggler = value; return 0; }
     if (!std::strcmp(key, "resident")) { s->opt_resident = value ? 1 : 0; return 0; }
+    if (!std::strcmp(key, "profile")) { s->opt_profile = value ? 1 : 0; return 0; }
     if (!std::strcmp(key, "trace_blocks_per_cu")) { if (value < 0 || value > 8) return sq_set_error("trace_blocks_per_cu must be in 0..8"); s->opt_trace_blocks_per_cu = value; return 0; }
     return sq_set_error("unknown option '%s'", key);
 }

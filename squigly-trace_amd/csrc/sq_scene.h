@@ -61,6 +61,22 @@ __device__ __forceinline__ bool slab(float lx, float ly, float lz, float hx, flo
     return tmax > 0 && tmin < tmax;
 }
 
+// The same test with hardware min/max.  Haskell's min/max differ from v_min_f32/v_max_f32 only when an
+// operand is NaN (and in the sign of a zero result, which no comparison below can see).  When the ray's
+// origin, direction and 1/direction are all finite, (bound - o) * df is finite or +-inf, never NaN, so
+// both forms return the same Bool.  `safe` rays use this form; any other ray uses slab().
+__device__ __forceinline__ bool slab_fast(float lx, float ly, float lz, float hx, float hy, float hz, f3 o, f3 df) {
+    const float t1 = (lx - o.x) * df.x, t2 = (hx - o.x) * df.x;
+    const float t3 = (ly - o.y) * df.y, t4 = (hy - o.y) * df.y;
+    const float t5 = (lz - o.z) * df.z, t6 = (hz - o.z) * df.z;
+    const float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t1, t2), __builtin_fminf(t3, t4)), __builtin_fminf(t5, t6));
+    const float tmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t1, t2), __builtin_fmaxf(t3, t4)), __builtin_fmaxf(t5, t6));
+    return tmax > 0 && tmin < tmax;
+}
+__device__ __forceinline__ bool finite3(f3 v) {
+    return __builtin_isfinite(v.x) && __builtin_isfinite(v.y) && __builtin_isfinite(v.z);
+}
+
 // mollerTrumbore (src/Geometry.hs:117-142) on (v0, e1, e2)
 __device__ __forceinline__ bool moller_trumbore(f3 o, f3 d, f3 v0, f3 e1, f3 e2, float& t_out, float& dist_out) {
     const float eps = 0.0001f;
@@ -178,21 +194,31 @@ struct HybridNodes {            // first n_lds branches (top of the tree) in LDS
 // edge1/edge2 (src/Geometry.hs:130-131) whether they were subtracted at upload or here.
 struct GlobalTris {
     const float4* t; const int2* leaves;
-    __device__ __forceinline__ void get(int i, f3& v0, f3& e1, f3& e2) const {
-        const float4 a = t[3 * i], b = t[3 * i + 1], c = t[3 * i + 2];
-        v0 = sq::mk(a.x, a.y, a.z); e1 = sq::mk(b.x, b.y, b.z); e2 = sq::mk(c.x, c.y, c.z);
+    struct Handle { int i; };
+    struct Raw { float4 a, b, c; };
+    __device__ __forceinline__ Handle handle(int i) const { return Handle{ i }; }
+    __device__ __forceinline__ Raw load(Handle h) const { return Raw{ t[3 * h.i], t[3 * h.i + 1], t[3 * h.i + 2] }; }
+    __device__ __forceinline__ void decode(const Raw& r, f3& v0, f3& e1, f3& e2) const {
+        v0 = sq::mk(r.a.x, r.a.y, r.a.z); e1 = sq::mk(r.b.x, r.b.y, r.b.z); e2 = sq::mk(r.c.x, r.c.y, r.c.z);
     }
+    __device__ __forceinline__ void get(int i, f3& v0, f3& e1, f3& e2) const { decode(load(handle(i)), v0, e1, e2); }
     __device__ __forceinline__ int2 leaf(uint32_t k) const { return leaves[k]; }
 };
 struct LdsTris {                // whole scene resident in LDS: indexed triangles + unique vertices
     const SQ_LDS float* verts; const SQ_LDS v4us* trix; const SQ_LDS v2i* leaves;
-    __device__ __forceinline__ void get(int i, f3& v0, f3& e1, f3& e2) const {
-        const v4us r = trix[i];
-        const SQ_LDS float* p0 = verts + 3 * r.x; const SQ_LDS float* p1 = verts + 3 * r.y; const SQ_LDS float* p2 = verts + 3 * r.z;
-        v0 = sq::mk(p0[0], p0[1], p0[2]);
-        e1 = sq::mk(p1[0], p1[1], p1[2]) - v0;
-        e2 = sq::mk(p2[0], p2[1], p2[2]) - v0;
+    struct Handle { v4us r; };
+    struct Raw { float p[9]; };
+    __device__ __forceinline__ Handle handle(int i) const { return Handle{ trix[i] }; }
+    __device__ __forceinline__ Raw load(Handle h) const {
+        const SQ_LDS float* p0 = verts + 3 * h.r.x; const SQ_LDS float* p1 = verts + 3 * h.r.y; const SQ_LDS float* p2 = verts + 3 * h.r.z;
+        return Raw{ { p0[0], p0[1], p0[2], p1[0], p1[1], p1[2], p2[0], p2[1], p2[2] } };
     }
+    __device__ __forceinline__ void decode(const Raw& r, f3& v0, f3& e1, f3& e2) const {
+        v0 = sq::mk(r.p[0], r.p[1], r.p[2]);
+        e1 = sq::mk(r.p[3], r.p[4], r.p[5]) - v0;
+        e2 = sq::mk(r.p[6], r.p[7], r.p[8]) - v0;
+    }
+    __device__ __forceinline__ void get(int i, f3& v0, f3& e1, f3& e2) const { decode(load(handle(i)), v0, e1, e2); }
     __device__ __forceinline__ int2 leaf(uint32_t k) const { const v2i l = leaves[k]; return make_int2(l.x, l.y); }
 };
 
@@ -201,12 +227,17 @@ struct Trav {
     uint32_t cur;
     int sp, mode;
     Hit R;
+    bool safe;          // o, d, 1/d all finite: slab_fast is exact for this ray
+    int csp;            // stack index of the COMBINE frame whose (t, dist) are cached below, or -1
+    float ct, cdist;
 };
 
 template <typename NodeSrc>
 __device__ __forceinline__ void trav_begin(Trav& T, const SceneView& S, f3 o, f3 d) {
     T.o = o; T.d = d; T.df = sq::mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     T.cur = S.root_ref; T.sp = 0; T.R.t = 0; T.R.dist = 0; T.R.tri = -1;
+    T.safe = finite3(o) && finite3(d) && finite3(T.df);
+    T.csp = -1; T.ct = 0; T.cdist = 0;
     T.mode = (T.cur & kLeafBit) ? M_LEAF : M_DESCEND;
     if (T.mode == M_DESCEND &&
         !slab(S.root_lo[0], S.root_lo[1], S.root_lo[2], S.root_hi[0], S.root_hi[1], S.root_hi[2], o, T.df))
@@ -221,8 +252,16 @@ __device__ __forceinline__ void trav_descend(Trav& T, const NodeSrc& N, SQ_LDS S
     const uint32_t left = __float_as_uint(q2.y), right = __float_as_uint(q2.z);
     const float lmax = q0.w, rmin = q1.w;
     // left = bbox with hi[ax] := lmax ; right = bbox with lo[ax] := rmin   (src/BIH.hs:130-141)
-    const bool iL = slab(q0.x, q0.y, q0.z, ax == 0 ? lmax : q1.x, ax == 1 ? lmax : q1.y, ax == 2 ? lmax : q1.z, T.o, T.df);
-    const bool iR = slab(ax == 0 ? rmin : q0.x, ax == 1 ? rmin : q0.y, ax == 2 ? rmin : q0.z, q1.x, q1.y, q1.z, T.o, T.df);
+    const float lhx = ax == 0 ? lmax : q1.x, lhy = ax == 1 ? lmax : q1.y, lhz = ax == 2 ? lmax : q1.z;
+    const float rlx = ax == 0 ? rmin : q0.x, rly = ax == 1 ? rmin : q0.y, rlz = ax == 2 ? rmin : q0.z;
+    bool iL, iR;
+    if (T.safe) {
+        iL = slab_fast(q0.x, q0.y, q0.z, lhx, lhy, lhz, T.o, T.df);
+        iR = slab_fast(rlx, rly, rlz, q1.x, q1.y, q1.z, T.o, T.df);
+    } else {
+        iL = slab(q0.x, q0.y, q0.z, lhx, lhy, lhz, T.o, T.df);
+        iR = slab(rlx, rly, rlz, q1.x, q1.y, q1.z, T.o, T.df);
+    }
     if (iL && iR) {
         const bool l2r = sq::axis_of(T.d, ax) > 0;                      // src/BIH.hs:127
         stk[T.sp * stride] = (StackT)T.cur; ++T.sp;                     // FAR(cur)
@@ -234,21 +273,24 @@ __device__ __forceinline__ void trav_descend(Trav& T, const NodeSrc& N, SQ_LDS S
 }
 
 // One triangle of a Leaf equation folded into R with minimumBy's rule (src/BIH.hs:105-109).
-template <typename TriSrc>
-__device__ __forceinline__ void leaf_fold(Trav& T, const TriSrc& G, int i) {
-    f3 v0, e1, e2;
-    G.get(i, v0, e1, e2);
+__device__ __forceinline__ void leaf_fold(Trav& T, f3 v0, f3 e1, f3 e2, int i) {
     float t, dist;
     if (moller_trumbore(T.o, T.d, v0, e1, e2, t, dist)) {
         if (T.R.tri < 0 || sq::cmp_gt(T.R.dist, dist)) { T.R.t = t; T.R.dist = dist; T.R.tri = i; }   // replace only on GT
     }
 }
-// The whole Leaf equation.  Pre: mode == M_LEAF.
+// The whole Leaf equation, triangles in leaf order.  Pre: mode == M_LEAF.
+// (A software-pipelined form that kept the next triangle's loads in flight measured 2 % slower with
+// the scene in LDS and 28 % slower from L2: the waves already hide that latency.)
 template <typename TriSrc>
 __device__ __forceinline__ void trav_leaf(Trav& T, const TriSrc& G) {
     const int2 lf = G.leaf(T.cur & ~kLeafBit);
     T.R.tri = -1;
-    for (int i = lf.x; i < lf.x + lf.y; ++i) leaf_fold(T, G, i);
+    for (int i = lf.x; i < lf.x + lf.y; ++i) {
+        f3 v0, e1, e2;
+        G.get(i, v0, e1, e2);
+        leaf_fold(T, v0, e1, e2, i);
+    }
     T.mode = M_UNWIND;
 }
 
@@ -261,10 +303,13 @@ __device__ __forceinline__ void trav_unwind(Trav& T, const NodeSrc& N, const Tri
     const uint32_t e = stk[T.sp * stride];
     if (e & flag) {                                                     // minimumByMay over [near, far] (src/BIH.hs:115,120)
         const int32_t ntri = (int32_t)(e & ~flag);
-        f3 v0, e1, e2;
-        G.get(ntri, v0, e1, e2);
-        float nt = 0, ndist = 0;
-        (void)moller_trumbore(T.o, T.d, v0, e1, e2, nt, ndist);
+        float nt = T.ct, ndist = T.cdist;
+        if (T.csp != T.sp) {                                            // not the cached (newest) frame: same bits from MT
+            f3 v0, e1, e2;
+            G.get(ntri, v0, e1, e2);
+            (void)moller_trumbore(T.o, T.d, v0, e1, e2, nt, ndist);
+        }
+        T.csp = -1;
         if (T.R.tri < 0 || !sq::cmp_gt(ndist, T.R.dist)) { T.R.t = nt; T.R.dist = ndist; T.R.tri = ntri; }   // ties keep near
         return;
     }
@@ -275,7 +320,8 @@ __device__ __forceinline__ void trav_unwind(Trav& T, const NodeSrc& N, const Tri
         const float p = sq::axis_of(T.o, ax) + T.R.t * sq::axis_of(T.d, ax);   // projectToAxis ax (intersectPoint near)
         const bool close = l2r ? (p < q1.w) : (p > q0.w);               // isClose, src/BIH.hs:121-123
         if (close) return;                                              // src/BIH.hs:114: the branch returns near
-        stk[T.sp * stride] = (StackT)((uint32_t)T.R.tri | flag); ++T.sp;   // COMBINE(R)
+        stk[T.sp * stride] = (StackT)((uint32_t)T.R.tri | flag);        // COMBINE(R)
+        T.csp = T.sp; T.ct = T.R.t; T.cdist = T.R.dist; ++T.sp;
     }
     T.cur = l2r ? __float_as_uint(q2.z) : __float_as_uint(q2.y);        // the far child
     T.mode = (T.cur & kLeafBit) ? M_LEAF : M_DESCEND;

@@ -53,6 +53,12 @@ class DeviceScene:
         N.check(N.lib().sq_kernel_timing(self._h, C.byref(ms), C.byref(n), C.byref(name)))
         return ms.value, n.value, (name.value or b"").decode()
 
+    def stats(self, reset=False):
+        """Cumulative trace-kernel statistics: [rays traced, profile counters...] (synchronises)."""
+        out = (C.c_uint64 * 16)()
+        N.check(N.lib().sq_get_stats(self._h, out, 16, int(reset)))
+        return [int(v) for v in out]
+
     def reset_timing(self):
         N.lib().sq_kernel_timing_reset(self._h)
 
