@@ -41,7 +41,8 @@ class Hit(C.Structure):
 
 class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in
-                ("samples", "rays", "branch_visits", "slab_tests", "leaf_visits", "tri_tests", "hits")]
+                ("samples", "rays", "branch_visits", "slab_tests", "leaf_visits", "tri_tests", "hits",
+                 "b_rays", "b_branch_visits", "b_tri_tests", "b_hits")]
 
     def asdict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

@@ -476,7 +476,13 @@ static V3 raytrace(const ctx_t* cx, const uint32_t* words, V3 o, V3 d, int bounc
     V3 black = v3(0, 0, 0);
     if (bounces > 2) return black;
     sqo_hit inter;
+    sqo_counters before = *cx->c;
     sqo_intersect_bih(cx->b, o, d, &inter, cx->c);
+    if (bounces >= 1) {
+        cx->c->b_rays++; cx->c->b_hits += cx->c->hits - before.hits;
+        cx->c->b_branch_visits += cx->c->branch_visits - before.branch_visits;
+        cx->c->b_tri_tests += cx->c->tri_tests - before.tri_tests;
+    }
     if (!inter.hit) return black;
     const sqo_triangle* tri = &cx->b->flat[inter.tri];
     sqo_material mat = tri->mat;
@@ -609,6 +615,8 @@ int sqo_render_rows_strided(const sqo_bih* b, const sqo_camera* cam, int n, int 
         tot.samples += jobs[t].c.samples; tot.rays += jobs[t].c.rays; tot.branch_visits += jobs[t].c.branch_visits;
         tot.slab_tests += jobs[t].c.slab_tests; tot.leaf_visits += jobs[t].c.leaf_visits;
         tot.tri_tests += jobs[t].c.tri_tests; tot.hits += jobs[t].c.hits;
+        tot.b_rays += jobs[t].c.b_rays; tot.b_branch_visits += jobs[t].c.b_branch_visits;
+        tot.b_tri_tests += jobs[t].c.b_tri_tests; tot.b_hits += jobs[t].c.b_hits;
     }
     if (counters) *counters = tot;
     free(jobs); free(th);

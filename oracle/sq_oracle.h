@@ -36,6 +36,8 @@ typedef struct {
     uint64_t leaf_visits;    /* intersectBIH' Leaf equations entered (src/BIH.hs:105) */
     uint64_t tri_tests;      /* mollerTrumbore calls (src/Geometry.hs:117) */
     uint64_t hits;           /* rays that returned Just (one material fetch each, src/Lib.hs:132) */
+    /* the same four for bounce rays only (raytrace called with bounces >= 1, src/Lib.hs:135) */
+    uint64_t b_rays, b_branch_visits, b_tri_tests, b_hits;
 } sqo_counters;
 
 /* trig_mode: how Float sin/cos/acos/atan are evaluated.
