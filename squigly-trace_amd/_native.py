@@ -51,6 +51,13 @@ def lib():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python squigly-trace_amd/build.py` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    # PyTorch (the plumbing for device buffers and streams) bundles its own HIP runtime.  It has to be the
+    # first HIP runtime loaded into the process: if libsquigly_hip.so pulls in the system one first, torch's
+    # later initialisation reports "No HIP GPUs are available".
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, i32, sz = C.c_void_p, C.c_int32, C.c_size_t
     L.sq_last_error.restype = C.c_char_p

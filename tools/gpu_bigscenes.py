@@ -1,0 +1,17 @@
+"""Timing of the stand-in scenes for BASELINE configs[2]/[4] on one GPU (informational)."""
+import importlib, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
+import gen_scenes as G
+sqt = importlib.import_module("squigly-trace_amd")
+import torch
+for name, (obj, sq, camt), (w, h, n) in (("blob6 (81932 tris)", G.blob_scene(6), (1920, 1080, 16)),
+                                          ("heightfield708 (1002540 tris)", G.heightfield_scene(708), (1920, 1080, 16))):
+    t = time.time(); bih = sqt.BIH(sqt.Mesh.from_text(obj, sq)); tb = time.time() - t
+    cam = sqt.camera_from_text(camt)
+    ds = sqt.DeviceScene(bih, 0)
+    ds.render_rows(cam, n, w, h); torch.cuda.synchronize(); ds.reset_timing(); ds.stats(reset=True)
+    t = time.time(); ds.render_rows(cam, n, w, h); torch.cuda.synchronize(); dt = time.time() - t
+    ms, cnt, kn = ds.kernel_timing(); rays = ds.stats()[0]
+    print(f"{name}: load+build {tb:.2f}s height {bih.height}; {w}x{h}@{n}: {w*h*n/dt/1e6:.1f} Msamples/s, {rays/dt/1e6:.1f} Mrays/s (trace {ms*cnt:.1f} of {dt*1e3:.1f} ms)", flush=True)
+    ds.close()
