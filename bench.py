@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--spp", type=int, default=256)
     ap.add_argument("--cpu-rows", type=int, default=96, help="rows of the frame timed on the CPU oracle")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and all_gather even with one rank (self-test)")
     args = ap.parse_args()
 
     import torch
@@ -71,8 +72,12 @@ def main():
         if rank == 0:
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     data = os.path.join(ROOT, "data")
@@ -86,7 +91,7 @@ def main():
         return d.render_frame(scene, cam, spp, w, h, want="rgb")
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -100,7 +105,7 @@ def main():
         frame = step()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -152,9 +157,9 @@ def main():
                                "note": "scene.obj (0.3 MB) is LDS/L2-resident: algorithmic bytes are served on chip, "
                                        "so frac can exceed 1; measured HBM bytes are in `traffic`"}
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
     scene.close()
+    if use_dist:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -5,6 +5,7 @@
 The flags that matter for bit-exact parity with the CPU oracle:
   -ffp-contract=off                               no FMA contraction (host and device)
   -fhip-fp32-correctly-rounded-divide-sqrt        IEEE fp32 divide / sqrt on the device
+  -fno-slp-vectorize                              performance only: packed fp32 VALU ops are slow on gfx950
   no -ffast-math, denormals kept (hipcc default for gfx9)
 """
 import os
@@ -18,6 +19,9 @@ SOURCES = ["sq_device.hip", "sq_host.cpp"]
 HEADERS = ["sq_math.h", "sq_error.h", "sq_scene.h", "../../include/squigly_hip.h", "../../include/squigly_host.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
          "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math",
+         # v_pk_mul_f32 / v_pk_add_f32 issue at ~9.5 cycles per wave on gfx950 against ~2.6 for the scalar forms
+         # (tools/ubench/valu_rate.hip): keep the SLP vectoriser from packing the fp32 vector math.
+         "-fno-slp-vectorize",
          "-Wall", "-Wno-unused-function"]
 
 

@@ -41,7 +41,7 @@ using namespace sqd;
 constexpr int kBlock = 256;        // per-pixel / per-sample kernels
 constexpr int kTraceBlock = 512;   // persistent trace kernel, streaming form: 8 waves share one LDS copy of the top of the tree
 constexpr int kResidentBlock = 1024; // persistent trace kernel, resident form: one workgroup per CU owns the whole scene in LDS
-constexpr int kChunk = 128;        // rays a wave reserves from the queue per atomic
+constexpr int kChunk = 128;        // rays a wave reserves from the queue per atomic (multiple of 64)
 
 // ----------------------------------------------------------------------------------------------
 // Frame description shared by the kernels
@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(kBlock) sq_render_pixels(const SceneView S, co
             const float dl = sq::norm(p0 - light);
             const Hit sh = trace_one(S, N, p0, light - p0, stk, kBlock);
             f3 c = sq::mk(0, 0, 0);
-            if (!(sh.tri >= 0 && !(sh.dist > dl))) c = sq::scale(2 / dl, s0.surf);
+            if (!(sh.tri >= 0 && !(hit_dist(p0, light - p0, sh.t) > dl))) c = sq::scale(2 / dl, s0.surf);
             for (int k = 0; k < n; ++k) sum = sum + c;
         } else {
             const long long rix = (long long)n * ((long long)x + (long long)y * (long long)F.w);   // src/Lib.hs:85
@@ -153,7 +153,7 @@ __global__ void __launch_bounds__(kBlock) sq_primary(const SceneView S, const Fr
     SQ_LDS StackT* stk = to_lds<StackT>(lds_raw) + threadIdx.x;
     const long long pix = (long long)blockIdx.x * kBlock + threadIdx.x;
     const bool in = pix < (long long)F.local_rows * F.h;
-    Hit h0; h0.tri = -1; h0.t = 0; h0.dist = 0;
+    Hit h0; h0.tri = -1; h0.t = 0;
     if (in) {
         int y, x; pixel_coords(F, pix, y, x);
         const GlobalNodes N{ S.branches };
@@ -287,17 +287,17 @@ struct TraceArgs {
                                  // [6] outer iterations (waves), [7] refill executions (waves), [8] lanes refilled
 };
 // LDS carve-up of the trace kernel (bytes, all 16-B aligned), shared by host and device.
-struct TraceLds { uint32_t nodes, leaves, verts, trix, live, stack, total; };
-__host__ __device__ inline TraceLds trace_lds_layout(int n_lds, bool resident, int n_leaves, int n_verts, int n_tris,
+struct TraceLds { uint32_t quads, refs, verts, trix, live, stack, total; };
+__host__ __device__ inline TraceLds trace_lds_layout(int n_lds, bool resident, int n_verts, int n_tris,
                                                      int block, int stack_cap, int stack_elem) {
     auto al = [](uint32_t b) { return (b + 15u) & ~15u; };
     TraceLds L; uint32_t off = 0;
-    L.nodes = off;  off += al((uint32_t)n_lds * 48u);
-    L.leaves = off; off += resident ? al((uint32_t)n_leaves * 8u) : 0u;
-    L.verts = off;  off += resident ? al((uint32_t)n_verts * 12u) : 0u;
-    L.trix = off;   off += resident ? al((uint32_t)n_tris * 8u) : 0u;
-    L.live = off;   off += al((uint32_t)(block / 64) * kChunk * 2u);
-    L.stack = off;  off += al((uint32_t)block * (uint32_t)stack_cap * (uint32_t)stack_elem);
+    L.quads = off; off += al((uint32_t)n_lds * (resident ? 32u : 48u));   // resident: 2 quads per branch; streaming: 3
+    L.refs = off;  off += resident ? al((uint32_t)n_lds * 8u) : 0u;
+    L.verts = off; off += resident ? al((uint32_t)n_verts * 16u) : 0u;
+    L.trix = off;  off += resident ? al((uint32_t)n_tris * 8u) : 0u;
+    L.live = off;  off += al((uint32_t)(block / 64) * kChunk * 2u);
+    L.stack = off; off += al((uint32_t)block * (uint32_t)stack_cap * (uint32_t)stack_elem);
     L.total = off;
     return L;
 }
@@ -311,30 +311,36 @@ template <typename StackT, bool RESIDENT, int BLOCK, bool PROFILE>
 __global__ void __launch_bounds__(BLOCK) sq_trace_rays(const SceneView S, const TraceArgs A) {
     extern __shared__ float4 lds_raw[];
     char* lds = reinterpret_cast<char*>(lds_raw);
-    const TraceLds L = trace_lds_layout(A.n_lds, RESIDENT, S.n_leaves, S.n_verts, S.n_tris, BLOCK, A.stack_cap, (int)sizeof(StackT));
-    SQ_LDS v4f* lnodes = to_lds<v4f>(lds + L.nodes);
+    const TraceLds L = trace_lds_layout(A.n_lds, RESIDENT, S.n_verts, S.n_tris, BLOCK, A.stack_cap, (int)sizeof(StackT));
     SQ_LDS uint16_t* live = to_lds<uint16_t>(lds + L.live) + (threadIdx.x >> 6) * kChunk;   // this wave's list
     SQ_LDS StackT* stk = to_lds<StackT>(lds + L.stack) + threadIdx.x;
-    for (int i = threadIdx.x; i < 3 * A.n_lds; i += BLOCK) { const float4 q = S.branches[i]; lnodes[i] = v4f{ q.x, q.y, q.z, q.w }; }   // coalesced 16-B loads
-    if (RESIDENT) {
-        SQ_LDS v2i* ll = to_lds<v2i>(lds + L.leaves);
-        SQ_LDS float* lv = to_lds<float>(lds + L.verts);
+    SQ_LDS v4f* lquads = to_lds<v4f>(lds + L.quads);
+    using NodeSrc = typename std::conditional<RESIDENT, ResidentNodes, HybridNodes>::type;
+    using TriSrc = typename std::conditional<RESIDENT, ResidentTris, GlobalTris>::type;
+    NodeSrc N; TriSrc G;
+    uint32_t root_ref;
+    if constexpr (RESIDENT) {                                         // stage the whole scene (coalesced loads)
+        SQ_LDS v2i* lrefs = to_lds<v2i>(lds + L.refs);
+        SQ_LDS v4f* lv = to_lds<v4f>(lds + L.verts);
         SQ_LDS v4us* lt = to_lds<v4us>(lds + L.trix);
-        for (int i = threadIdx.x; i < S.n_leaves; i += BLOCK) { const int2 l = S.leaves[i]; ll[i] = v2i{ l.x, l.y }; }
-        for (int i = threadIdx.x; i < 3 * S.n_verts; i += BLOCK) lv[i] = S.verts[i];
+        for (int i = threadIdx.x; i < A.n_lds; i += BLOCK) {
+            const uint32_t* r = S.rbranch + 10 * (size_t)i;
+            lquads[2 * i] = v4f{ __uint_as_float(r[0]), __uint_as_float(r[1]), __uint_as_float(r[2]), __uint_as_float(r[3]) };
+            lquads[2 * i + 1] = v4f{ __uint_as_float(r[4]), __uint_as_float(r[5]), __uint_as_float(r[6]), __uint_as_float(r[7]) };
+            lrefs[i] = v2i{ (int)r[8], (int)r[9] };
+        }
+        for (int i = threadIdx.x; i < S.n_verts; i += BLOCK) { const float4 v = S.verts4[i]; lv[i] = v4f{ v.x, v.y, v.z, v.w }; }
         for (int i = threadIdx.x; i < S.n_tris; i += BLOCK) { const ushort4 t = S.trix[i]; lt[i] = v4us{ t.x, t.y, t.z, t.w }; }
+        N = ResidentNodes{ lquads, lrefs };
+        G = ResidentTris{ lv, lt };
+        root_ref = S.rroot;
+    } else {
+        for (int i = threadIdx.x; i < 3 * A.n_lds; i += BLOCK) { const float4 q = S.branches[i]; lquads[i] = v4f{ q.x, q.y, q.z, q.w }; }
+        N = HybridNodes{ lquads, S.branches, (uint32_t)A.n_lds };
+        G = GlobalTris{ S.tris, S.leaves };
+        root_ref = S.root_ref;
     }
     __syncthreads();
-    using NodeSrc = typename std::conditional<RESIDENT, LdsNodes, HybridNodes>::type;
-    using TriSrc = typename std::conditional<RESIDENT, LdsTris, GlobalTris>::type;
-    NodeSrc N; TriSrc G;
-    if constexpr (RESIDENT) {
-        N = LdsNodes{ lnodes };
-        G = LdsTris{ to_lds<float>(lds + L.verts), to_lds<v4us>(lds + L.trix), to_lds<v2i>(lds + L.leaves) };
-    } else {
-        N = HybridNodes{ lnodes, S.branches, (uint32_t)A.n_lds };
-        G = GlobalTris{ S.tris, S.leaves };
-    }
     const long long n = (long long)(*A.n_active) * A.k_count;
     const int lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -345,7 +351,7 @@ __global__ void __launch_bounds__(BLOCK) sq_trace_rays(const SceneView S, const 
     unsigned long long n_traced = 0;        // wave-uniform
     unsigned long long pf_adv = 0, pf_leaf = 0, pf_outer = 0, pf_refill = 0;   // wave-uniform (PROFILE)
     unsigned int pl_unw = 0, pl_desc = 0, pl_tri = 0, pl_ref = 0;               // per lane (PROFILE)
-    Trav T; T.mode = M_DONE; T.sp = 0; T.cur = 0; T.R.tri = -1; T.R.t = 0; T.R.dist = 0;
+    Trav T; T.mode = M_DONE; T.sp = 0; T.cur = 0; T.R.tri = -1; T.R.t = 0;
     T.o = T.d = T.df = sq::mk(0, 0, 0);
     auto refill = [&](unsigned long long m, bool idle) {             // m = ballot(idle), wave-uniform
         while (!exhausted && list_pos == list_len) {                    // reserve and compact the next chunk
@@ -375,7 +381,7 @@ __global__ void __launch_bounds__(BLOCK) sq_trace_rays(const SceneView S, const 
             if (PROFILE) ++pl_ref;
             my_ray = chunk_base + live[list_pos + rank];
             const float4 o = A.org[my_ray], d = A.dir[my_ray];
-            trav_begin<NodeSrc>(T, S, sq::mk(o.x, o.y, o.z), sq::mk(d.x, d.y, d.z));
+            trav_begin(T, S, root_ref, sq::mk(o.x, o.y, o.z), sq::mk(d.x, d.y, d.z));
         }
         list_pos += min(__popcll(m), avail);
     };
@@ -400,7 +406,7 @@ __global__ void __launch_bounds__(BLOCK) sq_trace_rays(const SceneView S, const 
             if (T.mode == M_DESCEND) trav_descend(T, N, stk, BLOCK);
         }
         if (PROFILE) {
-            const int cnt = (T.mode == M_LEAF) ? G.leaf(T.cur & ~kLeafBit).y : 0;
+            const int cnt = (T.mode == M_LEAF) ? G.leaf(T.cur).y : 0;
             pl_tri += cnt; pf_leaf += wave_max(cnt);
         }
         if (T.mode == M_LEAF) trav_leaf(T, G);
@@ -441,7 +447,7 @@ __global__ void sq_debug_kernel(int op, const void* a, const void* b, long long 
 struct sq_device_scene {
     int device = 0;
     SceneView view{};
-    void *d_branches = nullptr, *d_leaves = nullptr, *d_tris = nullptr, *d_mats = nullptr, *d_verts = nullptr, *d_trix = nullptr;
+    void *d_branches = nullptr, *d_leaves = nullptr, *d_tris = nullptr, *d_mats = nullptr, *d_verts = nullptr, *d_trix = nullptr, *d_rbranch = nullptr;
     int height = 0; bool small_index = false; int n_cu = 256;
     // workspace (grow-only)
     Work work{}; void* d_work = nullptr; size_t work_bytes = 0; int64_t work_pixels = 0, work_slots = 0;
@@ -574,7 +580,7 @@ extern "C" int sq_scene_upload(const sq_scene* sc, int32_t device, sq_device_sce
                 if (it == ids.end()) {
                     if (ids.size() >= 65535) { fits = false; break; }
                     it = ids.emplace(key, (uint32_t)ids.size()).first;
-                    uverts.insert(uverts.end(), vs[k], vs[k] + 3);
+                    uverts.insert(uverts.end(), vs[k], vs[k] + 3); uverts.push_back(0.0f);
                 }
                 idx[(size_t)i * 3 + k] = it->second;
             }
@@ -586,6 +592,27 @@ extern "C" int sq_scene_upload(const sq_scene* sc, int32_t device, sq_device_sce
                 trix[(size_t)i * 4 + 3] = (uint16_t)sc->tris[i].mat;
             }
         } else { uverts.clear(); }
+    }
+    // Resident encoding of the branches (see sq_scene.h): needs encodable leaves and a 24-bit index space.
+    std::vector<uint32_t> rbranch; uint32_t rroot = 0;
+    {
+        bool ok = !trix.empty() && nb < (1 << 24) && sc->n_tris < (1 << 24);
+        for (int32_t i = 0; i < nl && ok; ++i) ok = lf[(size_t)i].count <= 31;
+        auto enc = [&](uint32_t r) -> uint32_t {
+            if (!(r & kLeafBit)) return r;
+            const DevLeaf& L = lf[r & ~kLeafBit];
+            return kLeafBit | ((uint32_t)L.count << 24) | (uint32_t)L.first;
+        };
+        if (ok) {
+            rbranch.resize((size_t)nb * 10);
+            for (int32_t i = 0; i < nb; ++i) {
+                const DevBranch& d = br[(size_t)i];
+                uint32_t* r = &rbranch[(size_t)i * 10];
+                std::memcpy(r, d.lo, 12); std::memcpy(r + 3, &d.lmax, 4); std::memcpy(r + 4, d.hi, 12); std::memcpy(r + 7, &d.rmin, 4);
+                r[8] = enc(d.left) | ((uint32_t)d.axis << 29); r[9] = enc(d.right);
+            }
+            rroot = enc(ref[0]);
+        } else { trix.clear(); }
     }
     SQ_HIP(hipSetDevice(device));
     sq_device_scene* s = new sq_device_scene;
@@ -600,7 +627,8 @@ extern "C" int sq_scene_upload(const sq_scene* sc, int32_t device, sq_device_sce
     };
     if (up(&s->d_branches, br.data(), br.size() * sizeof(DevBranch)) || up(&s->d_leaves, lf.data(), lf.size() * sizeof(DevLeaf)) ||
         up(&s->d_tris, tr.data(), tr.size() * sizeof(DevTri)) || up(&s->d_mats, mt.data(), mt.size() * sizeof(DevMat)) ||
-        up(&s->d_verts, uverts.data(), uverts.size() * sizeof(float)) || up(&s->d_trix, trix.data(), trix.size() * sizeof(uint16_t))) {
+        up(&s->d_verts, uverts.data(), uverts.size() * sizeof(float)) || up(&s->d_trix, trix.data(), trix.size() * sizeof(uint16_t)) ||
+        up(&s->d_rbranch, rbranch.data(), rbranch.size() * sizeof(uint32_t))) {
         sq_scene_free(s);
         return 1;
     }
@@ -611,7 +639,8 @@ extern "C" int sq_scene_upload(const sq_scene* sc, int32_t device, sq_device_sce
     v.root_ref = ref[0];
     v.n_branches = nb; v.n_leaves = nl; v.n_tris = sc->n_tris; v.n_mats = sc->n_mats;
     v.height = height; v.nonneg_materials = nonneg ? 1 : 0;
-    v.verts = (const float*)s->d_verts; v.trix = trix.empty() ? nullptr : (const ushort4*)s->d_trix; v.n_verts = (int32_t)(uverts.size() / 3);
+    v.verts4 = (const float4*)s->d_verts; v.trix = trix.empty() ? nullptr : (const ushort4*)s->d_trix; v.n_verts = (int32_t)(uverts.size() / 4);
+    v.rbranch = (const uint32_t*)s->d_rbranch; v.rroot = rroot;
     *out = s;
     return 0;
 }
@@ -620,7 +649,7 @@ extern "C" void sq_scene_free(sq_device_scene* s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
     for (auto& p : s->pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
-    (void)hipFree(s->d_branches); (void)hipFree(s->d_leaves); (void)hipFree(s->d_tris); (void)hipFree(s->d_mats); (void)hipFree(s->d_verts); (void)hipFree(s->d_trix);
+    (void)hipFree(s->d_branches); (void)hipFree(s->d_leaves); (void)hipFree(s->d_tris); (void)hipFree(s->d_mats); (void)hipFree(s->d_verts); (void)hipFree(s->d_trix); (void)hipFree(s->d_rbranch);
     (void)hipFree(s->d_work);
     delete s;
 }
@@ -708,7 +737,7 @@ int launch_frame(sq_device_scene* s, const Frame& F, hipStream_t stream) {
     bool resident = false;
     TraceLds L{};
     if (s->opt_resident && S.trix) {
-        L = trace_lds_layout(S.n_branches, true, S.n_leaves, S.n_verts, S.n_tris, kResidentBlock, stack_cap, (int)sizeof(StackT));
+        L = trace_lds_layout(S.n_branches, true, S.n_verts, S.n_tris, kResidentBlock, stack_cap, (int)sizeof(StackT));
         resident = L.total <= lds_budget;
     }
     int n_lds = S.n_branches, trace_blocks = 0, trace_threads = 0;
@@ -719,7 +748,7 @@ int launch_frame(sq_device_scene* s, const Frame& F, hipStream_t stream) {
     } else {
         const size_t max_node_bytes = 64 * 1024;                           // leave room for >= 2 workgroups per CU
         if ((size_t)n_lds * 48 > max_node_bytes) n_lds = (int)(max_node_bytes / 48);
-        L = trace_lds_layout(n_lds, false, S.n_leaves, S.n_verts, S.n_tris, kTraceBlock, stack_cap, (int)sizeof(StackT));
+        L = trace_lds_layout(n_lds, false, S.n_verts, S.n_tris, kTraceBlock, stack_cap, (int)sizeof(StackT));
         if (L.total > lds_budget) return sq_set_error("BIH height %d needs %u B of LDS per workgroup (max %zu)", S.height, L.total, lds_budget);
         trace_fn = s->opt_profile ? (const void*)sq_trace_rays<StackT, false, kTraceBlock, true> : (const void*)sq_trace_rays<StackT, false, kTraceBlock, false>;
         int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, lds_budget / L.total));

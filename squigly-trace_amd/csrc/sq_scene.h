@@ -42,14 +42,18 @@ struct SceneView {
     float root_lo[3], root_hi[3];
     uint32_t root_ref;
     int32_t n_branches, n_leaves, n_tris, n_mats;
-    const float* verts;       // unique vertices, 3 floats each (indexed form of the triangles, for LDS residency)
-    const ushort4* trix;      // per triangle: vertex indices i0,i1,i2 and material; nullptr if indices exceed 16 bits
+    // Resident (LDS) form of the same scene, present when it can be encoded (16-bit vertex indices, leaves
+    // of at most 31 triangles, < 2^24 triangles/branches): see "resident encoding" below.
+    const float4* verts4;     // unique vertices, 16 B each
+    const ushort4* trix;      // per triangle: vertex indices i0,i1,i2 and material; nullptr if not encodable
+    const uint32_t* rbranch;  // 10 words per branch: lo.xyz,lmax | hi.xyz,rmin | left word, right word
+    uint32_t rroot;           // root reference in resident encoding
     int32_t n_verts;
     int32_t height;           // BIH.height; a traversal never holds more than height-1 frames
     int32_t nonneg_materials; // 1 if every material component is >= +0 (enables the exact s == 0 shortcuts)
 };
 
-struct Hit { float t, dist; int32_t tri; };   // tri < 0 : Nothing
+struct Hit { float t; int32_t tri; };   // tri < 0 : Nothing.  dist is derived from t on demand (hit_dist)
 
 // intersectsBB (src/Geometry.hs:166-177) with df = 1/dir precomputed (the reference recomputes the same value)
 __device__ __forceinline__ bool slab(float lx, float ly, float lz, float hx, float hy, float hz, f3 o, f3 df) {
@@ -78,7 +82,7 @@ __device__ __forceinline__ bool finite3(f3 v) {
 }
 
 // mollerTrumbore (src/Geometry.hs:117-142) on (v0, e1, e2)
-__device__ __forceinline__ bool moller_trumbore(f3 o, f3 d, f3 v0, f3 e1, f3 e2, float& t_out, float& dist_out) {
+__device__ __forceinline__ bool moller_trumbore(f3 o, f3 d, f3 v0, f3 e1, f3 e2, float& t_out) {
     const float eps = 0.0001f;
     const f3 h = sq::cross(d, e2);
     const float a = sq::dot(e1, h);
@@ -92,10 +96,22 @@ __device__ __forceinline__ bool moller_trumbore(f3 o, f3 d, f3 v0, f3 e1, f3 e2,
     if (v < 0 || u + v > 1) return false;
     const float t = f * sq::dot(e2, q);
     if (!(t > eps)) return false;
-    const f3 p = o + sq::scale(t, d);
     t_out = t;
-    dist_out = sq::norm(p - o);
     return true;
+}
+// dist of an Intersection (src/Geometry.hs:134,141): norm ((o + t *^ d) - o), from the rounded hit point.
+__device__ __forceinline__ float hit_dist(f3 o, f3 d, float t) {
+    const f3 p = o + sq::scale(t, d);
+    return sq::norm(p - o);
+}
+// `compare (dist a) (dist b) == GT` for two hits of the SAME ray, given their t.
+// hit_dist is monotone non-decreasing in t: t*d_k, o_k + (.), (.) - o_k, squaring of a value whose sign is
+// fixed by d_k, the two additions and the square root are each monotone under round-to-nearest.  So
+// ta <= tb implies dist(a) <= dist(b), i.e. not GT, and the distances are only evaluated when ta > tb
+// (where equal rounded distances still give "not GT", exactly as the reference's tie rule needs).
+__device__ __forceinline__ bool dist_gt(f3 o, f3 d, float ta, float tb) {
+    if (!(ta > tb)) return false;
+    return sq::cmp_gt(hit_dist(o, d, ta), hit_dist(o, d, tb));
 }
 
 struct Surface {            // what shading needs from a hit triangle
@@ -164,7 +180,7 @@ __device__ __forceinline__ f3 primary_dir(const float* rot, int w, int h, int y,
 //     COMBINE(i)  = i | flag     "the near child of this branch returned the hit on triangle i; combine
 //                                 it with what the far child returns" (src/BIH.hs:115,120)
 // R is the value returned by the most recently finished call.  A COMBINE frame stores only the
-// triangle: its t and dist are recomputed with moller_trumbore, which returns the same bits.
+// triangle: its t is recomputed with moller_trumbore (same bits); dist is always derived from t.
 // NodeSrc supplies branch quads (LDS-staged or global); StackT is uint16_t when indices fit 15 bits.
 // ----------------------------------------------------------------------------------------------
 enum : int { M_DESCEND = 0, M_LEAF = 1, M_UNWIND = 2, M_DONE = 3 };
@@ -173,20 +189,38 @@ template <typename StackT> struct StackTraits;
 template <> struct StackTraits<uint16_t> { static constexpr uint32_t flag = 0x8000u; };
 template <> struct StackTraits<uint32_t> { static constexpr uint32_t flag = 0x80000000u; };
 
+// One branch as the traversal needs it.  Child references are opaque to the traversal except for
+// kLeafBit; the triangle source of the same kernel knows how to turn a leaf reference into a range.
+struct BranchData { v4f q0, q1; int axis; uint32_t left, right; };   // q0 = lo.xyz,lmax ; q1 = hi.xyz,rmin
+
+__device__ __forceinline__ BranchData unpack_branch(v4f q0, v4f q1, v4f q2) {
+    return BranchData{ q0, q1, __float_as_int(q2.x), __float_as_uint(q2.y), __float_as_uint(q2.z) };
+}
 struct GlobalNodes {            // every branch read from HBM/L2
     const float4* g;
-    __device__ __forceinline__ v4f quad(uint32_t b, int k) const { const float4 q = g[3 * b + k]; return v4f{ q.x, q.y, q.z, q.w }; }
-};
-struct LdsNodes {               // every branch staged in LDS (resident form)
-    const SQ_LDS v4f* l;
-    __device__ __forceinline__ v4f quad(uint32_t b, int k) const { return l[3 * b + k]; }
+    __device__ __forceinline__ BranchData load(uint32_t b) const {
+        const float4 a = g[3 * b], c = g[3 * b + 1], d = g[3 * b + 2];
+        return unpack_branch(v4f{ a.x, a.y, a.z, a.w }, v4f{ c.x, c.y, c.z, c.w }, v4f{ d.x, d.y, d.z, d.w });
+    }
 };
 struct HybridNodes {            // first n_lds branches (top of the tree) in LDS, the rest from HBM/L2
     const SQ_LDS v4f* l; const float4* g; uint32_t n_lds;
-    __device__ __forceinline__ v4f quad(uint32_t b, int k) const {
-        if (b < n_lds) return l[3 * b + k];
-        const float4 q = g[3 * b + k];
-        return v4f{ q.x, q.y, q.z, q.w };
+    __device__ __forceinline__ BranchData load(uint32_t b) const {
+        if (b < n_lds) return unpack_branch(l[3 * b], l[3 * b + 1], l[3 * b + 2]);
+        const float4 a = g[3 * b], c = g[3 * b + 1], d = g[3 * b + 2];
+        return unpack_branch(v4f{ a.x, a.y, a.z, a.w }, v4f{ c.x, c.y, c.z, c.w }, v4f{ d.x, d.y, d.z, d.w });
+    }
+};
+// Resident encoding (whole scene in LDS).  A branch is 40 B: two 16-B quads and two reference words.
+//   reference word: bit 31 = leaf; leaf: bits 28..24 = triangle count (<= 31), bits 23..0 = first triangle;
+//                   branch: bits 23..0 = branch index.  Bits 30..29 of the LEFT word hold the split axis.
+constexpr uint32_t kResAxisMask = 0x60000000u;
+struct ResidentNodes {
+    const SQ_LDS v4f* quads;      // 2 per branch
+    const SQ_LDS v2i* refs;       // 1 per branch
+    __device__ __forceinline__ BranchData load(uint32_t b) const {
+        const v2i r = refs[b];
+        return BranchData{ quads[2 * b], quads[2 * b + 1], (int)(((uint32_t)r.x >> 29) & 3u), (uint32_t)r.x & ~kResAxisMask, (uint32_t)r.y };
     }
 };
 
@@ -202,24 +236,18 @@ struct GlobalTris {
         v0 = sq::mk(r.a.x, r.a.y, r.a.z); e1 = sq::mk(r.b.x, r.b.y, r.b.z); e2 = sq::mk(r.c.x, r.c.y, r.c.z);
     }
     __device__ __forceinline__ void get(int i, f3& v0, f3& e1, f3& e2) const { decode(load(handle(i)), v0, e1, e2); }
-    __device__ __forceinline__ int2 leaf(uint32_t k) const { return leaves[k]; }
+    __device__ __forceinline__ int2 leaf(uint32_t ref) const { return leaves[ref & ~kLeafBit]; }
 };
-struct LdsTris {                // whole scene resident in LDS: indexed triangles + unique vertices
-    const SQ_LDS float* verts; const SQ_LDS v4us* trix; const SQ_LDS v2i* leaves;
-    struct Handle { v4us r; };
-    struct Raw { float p[9]; };
-    __device__ __forceinline__ Handle handle(int i) const { return Handle{ trix[i] }; }
-    __device__ __forceinline__ Raw load(Handle h) const {
-        const SQ_LDS float* p0 = verts + 3 * h.r.x; const SQ_LDS float* p1 = verts + 3 * h.r.y; const SQ_LDS float* p2 = verts + 3 * h.r.z;
-        return Raw{ { p0[0], p0[1], p0[2], p1[0], p1[1], p1[2], p2[0], p2[1], p2[2] } };
+struct ResidentTris {           // whole scene resident in LDS: 16-bit indexed triangles + unique vertices (16 B each)
+    const SQ_LDS v4f* verts; const SQ_LDS v4us* trix;
+    __device__ __forceinline__ void get(int i, f3& v0, f3& e1, f3& e2) const {
+        const v4us r = trix[i];
+        const v4f a = verts[r.x], b = verts[r.y], c = verts[r.z];
+        v0 = sq::mk(a.x, a.y, a.z);
+        e1 = sq::mk(b.x, b.y, b.z) - v0;
+        e2 = sq::mk(c.x, c.y, c.z) - v0;
     }
-    __device__ __forceinline__ void decode(const Raw& r, f3& v0, f3& e1, f3& e2) const {
-        v0 = sq::mk(r.p[0], r.p[1], r.p[2]);
-        e1 = sq::mk(r.p[3], r.p[4], r.p[5]) - v0;
-        e2 = sq::mk(r.p[6], r.p[7], r.p[8]) - v0;
-    }
-    __device__ __forceinline__ void get(int i, f3& v0, f3& e1, f3& e2) const { decode(load(handle(i)), v0, e1, e2); }
-    __device__ __forceinline__ int2 leaf(uint32_t k) const { const v2i l = leaves[k]; return make_int2(l.x, l.y); }
+    __device__ __forceinline__ int2 leaf(uint32_t ref) const { return make_int2((int)(ref & 0xFFFFFFu), (int)((ref >> 24) & 31u)); }
 };
 
 struct Trav {
@@ -228,16 +256,15 @@ struct Trav {
     int sp, mode;
     Hit R;
     bool safe;          // o, d, 1/d all finite: slab_fast is exact for this ray
-    int csp;            // stack index of the COMBINE frame whose (t, dist) are cached below, or -1
-    float ct, cdist;
+    int csp;            // stack index of the COMBINE frame whose t is cached below, or -1
+    float ct;
 };
 
-template <typename NodeSrc>
-__device__ __forceinline__ void trav_begin(Trav& T, const SceneView& S, f3 o, f3 d) {
+__device__ __forceinline__ void trav_begin(Trav& T, const SceneView& S, uint32_t root_ref, f3 o, f3 d) {
     T.o = o; T.d = d; T.df = sq::mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    T.cur = S.root_ref; T.sp = 0; T.R.t = 0; T.R.dist = 0; T.R.tri = -1;
+    T.cur = root_ref; T.sp = 0; T.R.t = 0; T.R.tri = -1;
     T.safe = finite3(o) && finite3(d) && finite3(T.df);
-    T.csp = -1; T.ct = 0; T.cdist = 0;
+    T.csp = -1; T.ct = 0;
     T.mode = (T.cur & kLeafBit) ? M_LEAF : M_DESCEND;
     if (T.mode == M_DESCEND &&
         !slab(S.root_lo[0], S.root_lo[1], S.root_lo[2], S.root_hi[0], S.root_hi[1], S.root_hi[2], o, T.df))
@@ -247,9 +274,10 @@ __device__ __forceinline__ void trav_begin(Trav& T, const SceneView& S, f3 o, f3
 // One Branch equation (src/BIH.hs:111-141).  Pre: mode == M_DESCEND.
 template <typename NodeSrc, typename StackT>
 __device__ __forceinline__ void trav_descend(Trav& T, const NodeSrc& N, SQ_LDS StackT* stk, int stride) {
-    const v4f q0 = N.quad(T.cur, 0), q1 = N.quad(T.cur, 1), q2 = N.quad(T.cur, 2);
-    const int ax = __float_as_int(q2.x);
-    const uint32_t left = __float_as_uint(q2.y), right = __float_as_uint(q2.z);
+    const BranchData B = N.load(T.cur);
+    const v4f q0 = B.q0, q1 = B.q1;
+    const int ax = B.axis;
+    const uint32_t left = B.left, right = B.right;
     const float lmax = q0.w, rmin = q1.w;
     // left = bbox with hi[ax] := lmax ; right = bbox with lo[ax] := rmin   (src/BIH.hs:130-141)
     const float lhx = ax == 0 ? lmax : q1.x, lhy = ax == 1 ? lmax : q1.y, lhz = ax == 2 ? lmax : q1.z;
@@ -274,9 +302,9 @@ __device__ __forceinline__ void trav_descend(Trav& T, const NodeSrc& N, SQ_LDS S
 
 // One triangle of a Leaf equation folded into R with minimumBy's rule (src/BIH.hs:105-109).
 __device__ __forceinline__ void leaf_fold(Trav& T, f3 v0, f3 e1, f3 e2, int i) {
-    float t, dist;
-    if (moller_trumbore(T.o, T.d, v0, e1, e2, t, dist)) {
-        if (T.R.tri < 0 || sq::cmp_gt(T.R.dist, dist)) { T.R.t = t; T.R.dist = dist; T.R.tri = i; }   // replace only on GT
+    float t;
+    if (moller_trumbore(T.o, T.d, v0, e1, e2, t)) {
+        if (T.R.tri < 0 || dist_gt(T.o, T.d, T.R.t, t)) { T.R.t = t; T.R.tri = i; }   // replace only on GT
     }
 }
 // The whole Leaf equation, triangles in leaf order.  Pre: mode == M_LEAF.
@@ -284,7 +312,7 @@ __device__ __forceinline__ void leaf_fold(Trav& T, f3 v0, f3 e1, f3 e2, int i) {
 // the scene in LDS and 28 % slower from L2: the waves already hide that latency.)
 template <typename TriSrc>
 __device__ __forceinline__ void trav_leaf(Trav& T, const TriSrc& G) {
-    const int2 lf = G.leaf(T.cur & ~kLeafBit);
+    const int2 lf = G.leaf(T.cur);
     T.R.tri = -1;
     for (int i = lf.x; i < lf.x + lf.y; ++i) {
         f3 v0, e1, e2;
@@ -303,27 +331,28 @@ __device__ __forceinline__ void trav_unwind(Trav& T, const NodeSrc& N, const Tri
     const uint32_t e = stk[T.sp * stride];
     if (e & flag) {                                                     // minimumByMay over [near, far] (src/BIH.hs:115,120)
         const int32_t ntri = (int32_t)(e & ~flag);
-        float nt = T.ct, ndist = T.cdist;
+        float nt = T.ct;
         if (T.csp != T.sp) {                                            // not the cached (newest) frame: same bits from MT
             f3 v0, e1, e2;
             G.get(ntri, v0, e1, e2);
-            (void)moller_trumbore(T.o, T.d, v0, e1, e2, nt, ndist);
+            (void)moller_trumbore(T.o, T.d, v0, e1, e2, nt);
         }
         T.csp = -1;
-        if (T.R.tri < 0 || !sq::cmp_gt(ndist, T.R.dist)) { T.R.t = nt; T.R.dist = ndist; T.R.tri = ntri; }   // ties keep near
+        if (T.R.tri < 0 || !dist_gt(T.o, T.d, nt, T.R.t)) { T.R.t = nt; T.R.tri = ntri; }   // ties keep near
         return;
     }
-    const v4f q0 = N.quad(e, 0), q1 = N.quad(e, 1), q2 = N.quad(e, 2);     // back in branch e: its near child returned R
-    const int ax = __float_as_int(q2.x);
+    const BranchData B = N.load(e);                                     // back in branch e: its near child returned R
+    const v4f q0 = B.q0, q1 = B.q1;
+    const int ax = B.axis;
     const bool l2r = sq::axis_of(T.d, ax) > 0;
     if (T.R.tri >= 0) {
         const float p = sq::axis_of(T.o, ax) + T.R.t * sq::axis_of(T.d, ax);   // projectToAxis ax (intersectPoint near)
         const bool close = l2r ? (p < q1.w) : (p > q0.w);               // isClose, src/BIH.hs:121-123
         if (close) return;                                              // src/BIH.hs:114: the branch returns near
         stk[T.sp * stride] = (StackT)((uint32_t)T.R.tri | flag);        // COMBINE(R)
-        T.csp = T.sp; T.ct = T.R.t; T.cdist = T.R.dist; ++T.sp;
+        T.csp = T.sp; T.ct = T.R.t; ++T.sp;
     }
-    T.cur = l2r ? __float_as_uint(q2.z) : __float_as_uint(q2.y);        // the far child
+    T.cur = l2r ? B.right : B.left;                                     // the far child
     T.mode = (T.cur & kLeafBit) ? M_LEAF : M_DESCEND;
 }
 
@@ -332,7 +361,7 @@ template <typename NodeSrc, typename StackT>
 __device__ __forceinline__ Hit trace_one(const SceneView& S, const NodeSrc& N, f3 o, f3 d, SQ_LDS StackT* stk, int stride) {
     const GlobalTris G{ S.tris, S.leaves };
     Trav T;
-    trav_begin<NodeSrc>(T, S, o, d);
+    trav_begin(T, S, S.root_ref, o, d);
     while (T.mode != M_DONE) {
         while (T.mode == M_DESCEND) trav_descend(T, N, stk, stride);
         if (T.mode == M_LEAF) trav_leaf(T, G);
