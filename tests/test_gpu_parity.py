@@ -240,3 +240,47 @@ def test_device_primitives_bit_exact(sqt, O):
     got = sqt.debug_eval("tonemap", c)
     want = np.array([O.tonemap(tuple(float(v) for v in row)) for row in c], np.uint8)
     assert np.array_equal(got, want)
+
+
+def test_axis_aligned_rays_take_the_exact_slab_path(sqt, O):
+    """A camera with zero Euler angles shoots dir = (1, xoffs, yoffs): the centre column has d.y == 0 and the
+    centre row d.z == 0, so 1/d is infinite, `(bound - o) * df` can be 0 * inf = NaN, and the traversal must
+    follow Haskell's min/max through NaN (slab(), not the v_min/v_max form).  Bit-equal to the oracle."""
+    cam_txt = b"-7 0.25 0.5\n0 0 0\n"
+    obj = open(os.path.join(DATA, "scene.obj"), "rb").read()
+    sq = open(os.path.join(DATA, "scene.sq"), "rb").read()
+    bih = sqt.BIH(sqt.Mesh.from_text(obj, sq))
+    ob = O.BIH(O.tris_from_text(obj, sq))
+    cam_p, cam_o = sqt.camera_from_text(cam_txt), O.camera_from_text(cam_txt)
+    d = O.make_ray(64, 64, 32, 32, cam_o)[1]
+    assert d[1] == 0.0 and d[2] == 0.0                      # the centre pixel looks exactly along +x
+    for (w, h, n, cast) in [(64, 64, 3, False), (33, 48, 2, False), (64, 64, 1, True)]:
+        g = sqt.render_f32(bih, cam_p, n, (w, h), cast=cast)
+        o, _, _ = ob.render(cam_o, n, w, h, cast=cast, threads=THREADS)
+        assert np.array_equal(bits(g), bits(o)), (w, h, n, cast)
+    assert ob.intersect(*O.make_ray(64, 64, 32, 32, cam_o)).hit == 1     # the axis-aligned centre ray does hit the scene
+
+
+def test_origin_on_box_planes_and_degenerate_directions(sqt, O):
+    """Rays that start exactly on slab planes with zero direction components (0 * inf = NaN in the slab test),
+    from a hand-made scene whose coordinates are exact in binary."""
+    sq = b"newmtl A\nreflective 0 1 1 1\nemissive 1 1 1 1\nnewmtl W\nreflective 0 0.5 0.5 0.5\nemissive 0 0 0 0\n"
+    rng = np.random.default_rng(5)
+    v = []
+    f = []
+    for i in range(40):                                     # 40 small axis-aligned quads on a lattice -> a real tree
+        cx, cy, cz = rng.integers(-4, 5, 3) * 0.5
+        base = len(v)
+        v += [(cx, cy, cz), (cx + 0.5, cy, cz), (cx + 0.5, cy + 0.5, cz), (cx, cy + 0.5, cz)]
+        f += [(base + 1, base + 2, base + 3), (base + 1, base + 3, base + 4)]
+    obj = b"mtllib s.sq\no Q\n" + b"".join(b"v %.1f %.1f %.1f\n" % (a, c, b) for a, b, c in v) + b"usemtl A\n" + \
+        b"".join(b"f %d %d %d\n" % t for t in f)
+    bih = sqt.BIH(sqt.Mesh.from_text(obj, sq))
+    ob = O.BIH(O.tris_from_text(obj, sq))
+    assert bih.height > 1
+    for cam_txt in (b"-2 0 0.5\n0 0 0\n", b"0 -2 0\n1.5707963267948966 0 0\n", b"-2.5 -2 -2\n0 0 0\n"):
+        cam_p, cam_o = sqt.camera_from_text(cam_txt), O.camera_from_text(cam_txt)
+        for cast in (False, True):
+            g = sqt.render_f32(bih, cam_p, 2, (32, 32), cast=cast)
+            o, _, _ = ob.render(cam_o, 2, 32, 32, cast=cast, threads=4)
+            assert np.array_equal(bits(g), bits(o)), (cam_txt, cast)

@@ -155,3 +155,29 @@ def test_product_does_not_touch_the_oracle():
                 assert "/root/reference" not in text
     ldd = subprocess.check_output(["ldd", os.path.join(pkg, "libsquigly_hip.so")]).decode()
     assert "oracle" not in ldd
+
+
+def test_hit_distance_is_monotone_in_t():
+    """The trace kernel compares two hits of one ray by t first and evaluates dist = norm((o + t*d) - o) only when
+    t does not decide (csrc/sq_scene.h: dist_gt).  That rests on dist being monotone non-decreasing in t under
+    round-to-nearest fp32; check it on adjacent and random t pairs, including tiny, huge and mixed-sign inputs."""
+    rng = np.random.default_rng(3)
+    f = np.float32
+
+    def dist(o, d, t):
+        p = o + t[:, None] * d
+        v = p - o
+        return np.sqrt((v[:, 0] * v[:, 0] + v[:, 1] * v[:, 1]) + v[:, 2] * v[:, 2], dtype=np.float32)
+
+    n = 400000
+    scale = (10.0 ** rng.uniform(-6, 6, (n, 1))).astype(f)
+    o = (rng.normal(size=(n, 3)) * scale).astype(f)
+    d = (rng.normal(size=(n, 3)) * (10.0 ** rng.uniform(-3, 3, (n, 1)))).astype(f)
+    d[rng.random(n) < 0.1, 0] = 0
+    d[rng.random(n) < 0.1, 1] = -0.0
+    t1 = (10.0 ** rng.uniform(-4, 4, n)).astype(f)
+    for t2 in (np.nextafter(t1, f(np.inf)), (t1 * (1 + 10.0 ** rng.uniform(-7, 0, n))).astype(f), (t1 + f(1e-4)).astype(f)):
+        with np.errstate(over="ignore", invalid="ignore"):
+            d1, d2 = dist(o, d, t1), dist(o, d, t2.astype(f))
+        assert np.all(t2 >= t1)
+        assert np.all(d2 >= d1), int((d2 < d1).sum())
