@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libsquigly_hip.so")
 SOURCES = ["sq_device.hip", "sq_host.cpp"]
-HEADERS = ["sq_math.h", "sq_error.h", "sq_scene.h", "../../include/squigly_hip.h", "../../include/squigly_host.h"]
+HEADERS = ["sq_math.h", "sq_error.h", "sq_scene.h", "cli_main.cpp", "../../include/squigly_hip.h", "../../include/squigly_host.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
          "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math",
          # v_pk_mul_f32 / v_pk_add_f32 issue at ~9.5 cycles per wave on gfx950 against ~2.6 for the scalar forms
@@ -40,11 +40,19 @@ def stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+CLI = os.path.join(HERE, "bin", "squigly-trace")
+
+
 def build(force=False, extra=()):
-    if not force and not stale():
+    if not force and not stale() and os.path.exists(CLI):
         return OUT
     cmd = [hipcc()] + FLAGS + list(extra) + ["-x", "hip"] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", OUT]
     subprocess.check_call(cmd)
+    # the reference's executable (app/Main.hs) over the C-ABI
+    os.makedirs(os.path.dirname(CLI), exist_ok=True)
+    subprocess.check_call(["g++", "-O2", "-std=c++17", os.path.join(CSRC, "cli_main.cpp"), "-o", CLI,
+                           "-L" + HERE, "-lsquigly_hip", "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath,/opt/rocm/lib",
+                           "-Wl,--allow-shlib-undefined"])
     return OUT
 
 

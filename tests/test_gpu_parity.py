@@ -97,7 +97,12 @@ def test_small_degenerate_and_empty_scenes(sqt, O):
                              b"o M\nv -3 -3 -3\nv 3 -3 -3\nv 0 -3 3\nusemtl M\nf 4 5 6\n"),
     }
     cam_p, cam_o = sqt.camera_from_text(cam_txt), O.camera_from_text(cam_txt)
-    for name, obj in scenes.items():
+    # a material file with NEGATIVE components switches off the exact `surfColor == 0` shortcuts (they are
+    # only identities when every radiance is >= +0): both code paths must equal the oracle
+    sq_neg = sq.replace(b"emissive 1 1 1 1", b"emissive 1 1 -0.5 1").replace(b"reflective 1 0.9 0.9 0.9", b"reflective 1 0.9 -0.9 0")
+    for name, obj in list(scenes.items()) + [("negative-materials", scenes["mirror-and-light"])]:
+        if name == "negative-materials":
+            sq = sq_neg
         bih = sqt.BIH(sqt.Mesh.from_text(obj, sq))
         ob = O.BIH(O.tris_from_text(obj, sq))
         for cast in (False, True):
@@ -284,3 +289,37 @@ def test_origin_on_box_planes_and_degenerate_directions(sqt, O):
             g = sqt.render_f32(bih, cam_p, 2, (32, 32), cast=cast)
             o, _, _ = ob.render(cam_o, 2, 32, 32, cast=cast, threads=4)
             assert np.array_equal(bits(g), bits(o)), (cam_txt, cast)
+
+
+def test_cpp_cli_writes_the_golden_image(sqt, tmp_path):
+    """The C++ `squigly-trace` executable (app/Main.hs flags over the C-ABI) renders data/scene.obj and writes a PNG
+    whose pixels are the golden RGB8 fixture; the Python CLI mirror does the same."""
+    import subprocess
+    from PIL import Image
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "squigly-trace_amd", "bin", "squigly-trace")
+    assert os.path.exists(exe), "build() must produce the CLI"
+    gold = np.load(os.path.join(GOLDEN, "scene_64x64_4spp_rgb8.npy"))
+    out = str(tmp_path / "cli.png")
+    r = subprocess.run([exe, "-s", "4", "--dimensions=64,64", "-p", out, "--debug"], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "BIH height is 13" in r.stdout and "Number of leaves is 640" in r.stdout and "Took " in r.stdout
+    assert np.array_equal(np.array(Image.open(out).convert("RGB")), gold)
+    # cast mode through the same binary
+    gold_cast = np.load(os.path.join(GOLDEN, "scene_64x64_cast_rgb8.npy"))
+    r = subprocess.run([exe, "-s", "2", "-d", "64,64", "--savepath", out, "--cast"], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert np.array_equal(np.array(Image.open(out).convert("RGB")), gold_cast)
+    # error behaviour: unknown file
+    r = subprocess.run([exe, "--objpath", "/nonexistent.obj"], cwd=ROOT, capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "cannot open" in r.stderr
+    # Python mirror of the CLI
+    import importlib
+    cli = importlib.import_module("squigly-trace_amd.cli")
+    cwd = os.getcwd()
+    os.chdir(ROOT)
+    try:
+        assert cli.main(["-s", "4", "-d", "64,64", "-p", out]) == 0
+    finally:
+        os.chdir(cwd)
+    assert np.array_equal(np.array(Image.open(out).convert("RGB")), gold)
