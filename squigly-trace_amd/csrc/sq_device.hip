@@ -9,12 +9,13 @@
 //   atan tonemap                     src/Lib.hs:93-104                       sq_accumulate
 //
 // Pipeline ("wavefront" form of renderPixel):  every sample of a pixel shoots the same primary ray
-// (src/Lib.hs:81-87), so it is traced once per pixel; pixels that hit are compacted; then, per batch
-// of samples, bounce rays are generated into a queue, traced by a persistent kernel whose lanes pull
-// the next ray as soon as theirs finishes, shaded, compacted (wave ballot + prefix) into the second
-// bounce queue, traced again, and folded into per-sample radiances that are summed per pixel in
-// sample order.  Every value is computed by the same fp32 expression tree as the reference.
-// An alternative one-lane-per-pixel kernel (sq_render_pixels) is kept as a cross-check variant.
+// (src/Lib.hs:81-87), so it is traced once per pixel and the pixels that hit are compacted (wave ballot +
+// prefix rank).  Then, per batch of samples, every sample owns one slot: its first bounce ray is generated
+// into the slot, traced by a persistent kernel (which compacts live slots on the fly and lets a lane pull
+// its next ray as soon as the previous one finishes), shaded, replaced in place by the second bounce ray,
+// traced again, and folded into a per-sample radiance; radiances are summed per pixel in sample order.
+// Every value is computed by the same fp32 expression tree as the reference.
+// The one-lane-per-pixel kernel sq_render_pixels serves raycast mode and is a cross-check variant.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -455,7 +456,7 @@ struct sq_device_scene {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
     double total_ms = 0; int64_t launches = 0;
     // options
-    int64_t opt_timing = 1, opt_variant = 2, opt_slots = 48ll << 20, opt_straggler = 6, opt_trace_blocks_per_cu = 0, opt_resident = 1, opt_profile = 0;
+    int64_t opt_timing = 1, opt_variant = 2, opt_slots = 48ll << 20, opt_straggler = 6, opt_trace_blocks_per_cu = 0, opt_resident = 1, opt_profile = 0, opt_lds_node_kb = 32;
     const char* last_kernel = "sq_trace_rays";
 };
 
@@ -746,7 +747,7 @@ int launch_frame(sq_device_scene* s, const Frame& F, hipStream_t stream) {
         trace_fn = s->opt_profile ? (const void*)sq_trace_rays<StackT, true, kResidentBlock, true> : (const void*)sq_trace_rays<StackT, true, kResidentBlock, false>;
         trace_blocks = s->n_cu; trace_threads = kResidentBlock;
     } else {
-        const size_t max_node_bytes = 64 * 1024;                           // leave room for >= 2 workgroups per CU
+        const size_t max_node_bytes = (size_t)s->opt_lds_node_kb * 1024;     // top of the tree; the rest of LDS buys occupancy
         if ((size_t)n_lds * 48 > max_node_bytes) n_lds = (int)(max_node_bytes / 48);
         L = trace_lds_layout(n_lds, false, S.n_verts, S.n_tris, kTraceBlock, stack_cap, (int)sizeof(StackT));
         if (L.total > lds_budget) return sq_set_error("BIH height %d needs %u B of LDS per workgroup (max %zu)", S.height, L.total, lds_budget);
@@ -839,6 +840,7 @@ extern "C" int sq_set_option(sq_device_scene* s, const char* key, int64_t value)
     if (!std::strcmp(key, "straggler_lanes")) { if (value < 0 || value > 63) return sq_set_error("straggler_lanes must be in 0..63"); s->opt_straggler = value; return 0; }
     if (!std::strcmp(key, "resident")) { s->opt_resident = value ? 1 : 0; return 0; }
     if (!std::strcmp(key, "profile")) { s->opt_profile = value ? 1 : 0; return 0; }
+    if (!std::strcmp(key, "lds_node_kb")) { if (value < 0 || value > 128) return sq_set_error("lds_node_kb must be in 0..128"); s->opt_lds_node_kb = value; return 0; }
     if (!std::strcmp(key, "trace_blocks_per_cu")) { if (value < 0 || value > 8) return sq_set_error("trace_blocks_per_cu must be in 0..8"); s->opt_trace_blocks_per_cu = value; return 0; }
     return sq_set_error("unknown option '%s'", key);
 }
@@ -851,7 +853,6 @@ int render_oneshot(const sq_scene* scene, const sq_camera* cam, int32_t samples,
     if (samples < 1 || w < 1 || h < 1) return sq_set_error("samples, width and height must be positive (got %d, %d, %d)", samples, w, h);
     sq_device_scene* s = nullptr;
     if (sq_scene_upload(scene, 0, &s)) return 1;
-    if (const char* v = std::getenv("SQ_VARIANT")) s->opt_variant = (std::atoi(v) == 1) ? 1 : 2;
     const size_t npx = (size_t)w * (size_t)h * 3;
     float* d_avg = nullptr; uint8_t* d_rgb = nullptr;
     std::vector<float> h_avg; std::vector<uint8_t> h_rgb;

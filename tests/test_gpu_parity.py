@@ -323,3 +323,24 @@ def test_cpp_cli_writes_the_golden_image(sqt, tmp_path):
     finally:
         os.chdir(cwd)
     assert np.array_equal(np.array(Image.open(out).convert("RGB")), gold)
+
+
+def test_config_c4_shard_of_eight(sqt, product_scene, oracle_scene, dev):
+    """BASELINE configs[3]: 3840x2160 @ 1024 spp tiled over 8 GPUs.  One rank's shard (rank 3 of 8, interleaved
+    blocks of 8 rows) is rendered on this GPU; two of its rows are compared with the oracle bit for bit.
+    Seeds reach 1024*(2159 + 3839*3840) = 1.5e10 > 2^32 here."""
+    import torch
+    from importlib import import_module
+    d = import_module("squigly-trace_amd.dist")
+    bih, cam, _ = product_scene
+    ob, ocam, _ = oracle_scene
+    w, h, n, rank, world = 3840, 2160, 1024, 3, 8
+    rows = d.shard_rows(w, d.ROW_BLOCK, rank, world)
+    avg, rgb = dev.render_rows(cam, n, w, h, shard=(d.ROW_BLOCK, rank, world))
+    torch.cuda.synchronize()
+    assert avg.shape == (len(rows), h, 3) and len(rows) == w // world
+    for j in (5, 300):
+        y = rows[j]
+        o, o8, _ = ob.render(ocam, n, w, h, threads=THREADS, rows=(y, y + 1))
+        assert np.array_equal(bits(avg[j:j + 1].cpu().numpy()), bits(o)), y
+        assert np.array_equal(rgb[j:j + 1].cpu().numpy(), o8)
