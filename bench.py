@@ -60,6 +60,10 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and all_gather even with one rank (self-test)")
     args = ap.parse_args()
 
+    if not args.no_cpu and int(os.environ.get("RANK", "0")) == 0:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import pyoracle
+        pyoracle.lib()                        # load (or build) the CPU checker before the GPU is initialised
     import torch
     import torch.distributed as dist
     sqt = importlib.import_module("squigly-trace_amd")

@@ -16,6 +16,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _load_native_code_first():
+    """Build/load both shared libraries before any test can initialise the GPU (no process spawning after that)."""
+    import pyoracle
+    pyoracle.lib()
+    mod = importlib.import_module("squigly-trace_amd")
+    if not os.path.exists(mod.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    mod.lib()
+
+
 @pytest.fixture(scope="session")
 def O():
     """The CPU oracle (checker only)."""
