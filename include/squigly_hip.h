@@ -83,7 +83,15 @@ void sq_kernel_timing_reset(sq_device_scene* s);
 /* Cumulative statistics of the trace kernel since the last reset (synchronises the device):
  * out[0] = rays traced; out[1..8] = lane-occupancy counters, filled only with option "profile" = 1. */
 int  sq_get_stats(sq_device_scene* s, uint64_t* out, int32_t n, int32_t reset);
-/* Tunables (0 = library default). variant selects a kernel implementation; all produce identical bits. */
+/* Tunables; every setting produces identical bits.  Keys:
+ *   "variant"            1 = one-lane-per-pixel kernel, 2 = wavefront pipeline (default)
+ *   "slots"              sample slots of the frame workspace (default 48 Mi; 60 B each)
+ *   "resident"           1 = keep the whole scene in LDS when it fits (default), 0 = always stream
+ *   "lds_node_kb"        streaming form: KB of LDS for the top of the tree (default 32)
+ *   "straggler_lanes"    lanes still traversing when a wave turns to its leaves (default 6)
+ *   "trace_blocks_per_cu" streaming form: workgroups per CU (0 = as many as LDS allows, up to 4)
+ *   "timing"             1 = bracket the dominant kernel with hipEvents (default)
+ *   "profile"            1 = lane-occupancy counters in sq_get_stats (slower) */
 int  sq_set_option(sq_device_scene* s, const char* key, int64_t value);
 
 /* Diagnostics for the numeric spec (tests only): evaluate one primitive on the device for n inputs.

@@ -123,6 +123,8 @@ struct Work {                 // device workspace of one frame (HBM)
     float*   px_t0;           // primary hit: t
     int32_t* px_tri0;         // primary hit: triangle
     float*   px_sum;          // running ordered sum of sample radiances, 3 floats
+    float*   px_mt;           // hit of the pixel's MIRROR bounce ray (reflectRay has no random input, so every
+    int32_t* px_mtri;         //   sample of the pixel that mirrors at depth 0 shoots this same ray): t, triangle (-1 = miss)
     // per sample slot sid = k_local * A + a : the ray queue is dense in sid, dead entries are flagged
     float4*  org;             // ray origin.xyz ; w = kLive / kDead
     float4*  dir;             // ray direction.xyz ; w = triangle hit by ray 1 (second bounce level)
@@ -133,7 +135,7 @@ struct Work {                 // device workspace of one frame (HBM)
     unsigned long long* stats;  // cumulative trace-kernel statistics (TraceArgs::stats)
     int64_t  slot_capacity;
 };
-constexpr float kLive = 1.0f, kDead = -1.0f;
+constexpr float kLive = 1.0f, kDead = -1.0f, kMirror = -2.0f;   // kMirror: finished tracing, result is the pixel's mirror hit
 
 // Appends `want` lanes of this wave to a list with one atomic: wave ballot + prefix rank.
 __device__ __forceinline__ int wave_append(int32_t* counter, bool want) {
@@ -202,9 +204,34 @@ __global__ void __launch_bounds__(kBlock) sq_gen_bounce1(const SceneView S, cons
         uint32_t n0, n1, n2;
         sq::tfgen3(rix + k, n0, n1, n2);                                // mkTFGen (rix + k), src/Lib.hs:86
         W.rng12[sid] = make_uint2(n1, n2);
-        const f3 d1 = bounce_dir(P.d0, P.s0, n0, n1);
+        if (!scatters(P.s0, n0)) {                                      // mirror: traced once per pixel (sq_mirror1_*)
+            W.org[sid] = make_float4(P.p0.x, P.p0.y, P.p0.z, kMirror);
+            continue;
+        }
+        const f3 d1 = scatter_dir(P.d0, P.s0, n0, n1);
         W.org[sid] = make_float4(P.p0.x, P.p0.y, P.p0.z, kLive);
         W.dir[sid] = make_float4(d1.x, d1.y, d1.z, 0.0f);
+    }
+}
+
+// The depth-0 mirror ray of every active pixel, once per frame (slot a = active pixel a).
+__global__ void __launch_bounds__(kBlock) sq_mirror1_gen(const SceneView S, const Frame F, const Work W) {
+    const int A = *W.n_active;
+    for (int a = blockIdx.x * kBlock + threadIdx.x; a < A; a += gridDim.x * kBlock) {
+        const Pixel0 P = load_pixel0(S, F, W, a);
+        if (absorbs(S, P.s0)) { W.org[a] = make_float4(0, 0, 0, kDead); continue; }
+        const f3 d1 = mirror_dir(P.d0, P.s0);
+        W.org[a] = make_float4(P.p0.x, P.p0.y, P.p0.z, kLive);
+        W.dir[a] = make_float4(d1.x, d1.y, d1.z, 0.0f);
+    }
+}
+__global__ void __launch_bounds__(kBlock) sq_mirror1_store(const Work W) {
+    const int A = *W.n_active;
+    for (int a = blockIdx.x * kBlock + threadIdx.x; a < A; a += gridDim.x * kBlock) {
+        const bool live = W.org[a].w >= 0.0f;
+        const int2 hit = W.hit[a];
+        W.px_mt[a] = live ? __int_as_float(hit.x) : 0.0f;
+        W.px_mtri[a] = live ? hit.y : -1;
     }
 }
 
@@ -214,8 +241,19 @@ __global__ void __launch_bounds__(kBlock) sq_shade1(const SceneView S, const Fra
     const long long total = (long long)A * k_count;
     for (long long sid = (long long)blockIdx.x * kBlock + threadIdx.x; sid < total; sid += (long long)gridDim.x * kBlock) {
         const float4 org = W.org[sid];
-        if (org.w < 0) continue;
-        const int2 hit = W.hit[sid];
+        if (org.w == kDead) continue;
+        const bool mirrored = (org.w == kMirror);
+        int2 hit; f3 d1;
+        if (mirrored) {                                                 // the pixel's mirror ray and its hit
+            const int a = (int)(sid % A);
+            const Pixel0 P = load_pixel0(S, F, W, a);
+            d1 = mirror_dir(P.d0, P.s0);
+            hit = make_int2(__float_as_int(W.px_mt[a]), W.px_mtri[a]);
+        } else {
+            const float4 dir = W.dir[sid];
+            d1 = sq::mk(dir.x, dir.y, dir.z);
+            hit = W.hit[sid];
+        }
         const int tri1 = hit.y;
         if (tri1 < 0) {                                                 // raytrace ... 1 = black
             const Surface s0 = surface_of(S, W.px_tri0[sid % A]);
@@ -231,8 +269,6 @@ __global__ void __launch_bounds__(kBlock) sq_shade1(const SceneView S, const Fra
             W.org[sid].w = kDead;
             continue;
         }
-        const float4 dir = W.dir[sid];
-        const f3 d1 = sq::mk(dir.x, dir.y, dir.z);
         const f3 p1 = sq::mk(org.x, org.y, org.z) + sq::scale(__int_as_float(hit.x), d1);
         const uint2 r = W.rng12[sid];
         const f3 d2 = bounce_dir(d1, s1, r.x, r.y);                     // gen advanced by one: x = u = p(n1), v = p(n2)
@@ -682,6 +718,7 @@ int ensure_workspace(sq_device_scene* s, int64_t pixels, int64_t slots) {
     const size_t o_cnt = take(64 * sizeof(int32_t));
     const size_t o_stats = take(16 * sizeof(unsigned long long));
     const size_t o_pix = take(pixels * 4), o_t0 = take(pixels * 4), o_tri0 = take(pixels * 4), o_sum = take(pixels * 12);
+    const size_t o_mt = take(pixels * 4), o_mtri = take(pixels * 4);
     const size_t o_org = take(slots * 16), o_dir = take(slots * 16), o_hit = take(slots * 8), o_rng = take(slots * 8), o_rad = take(slots * 12);
     if (s->d_work) { (void)hipFree(s->d_work); s->d_work = nullptr; }
     if (hipMalloc(&s->d_work, off) != hipSuccess) return sq_set_error("hipMalloc(%zu B) for the frame workspace failed", off);
@@ -692,6 +729,7 @@ int ensure_workspace(sq_device_scene* s, int64_t pixels, int64_t slots) {
     W.stats = (unsigned long long*)(base + o_stats);
     if (hipMemset(W.stats, 0, 16 * sizeof(unsigned long long)) != hipSuccess) return sq_set_error("hipMemset failed");
     W.px_pixel = (int32_t*)(base + o_pix); W.px_t0 = (float*)(base + o_t0); W.px_tri0 = (int32_t*)(base + o_tri0); W.px_sum = (float*)(base + o_sum);
+    W.px_mt = (float*)(base + o_mt); W.px_mtri = (int32_t*)(base + o_mtri);
     W.org = (float4*)(base + o_org); W.dir = (float4*)(base + o_dir); W.hit = (int2*)(base + o_hit);
     W.rng12 = (uint2*)(base + o_rng); W.rad = (float*)(base + o_rad);
     W.slot_capacity = slots;
@@ -759,17 +797,27 @@ int launch_frame(sq_device_scene* s, const Frame& F, hipStream_t stream) {
     const size_t tr_lds = L.total;
     if (tr_lds > 64 * 1024) SQ_HIP(hipFuncSetAttribute(trace_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tr_lds));
     const int aux_blocks = s->n_cu * 8;
+    auto launch_trace = [&](int kc, int level) -> int {
+        TraceArgs A{ W.org, W.dir, W.hit, W.n_active, kc, W.head[level], n_lds, stack_cap, (int32_t)s->opt_straggler, W.stats };
+        return timed([&] {
+            void* kargs[] = { (void*)&S, (void*)&A };
+            (void)hipLaunchKernel(trace_fn, dim3(trace_blocks), dim3(trace_threads), kargs, tr_lds, stream);
+        }, "sq_trace_rays");
+    };
+    // once per frame: the depth-0 mirror ray of every active pixel (reused by every sample that mirrors)
+    SQ_HIP(hipMemsetAsync(W.head[0], 0, 32 * sizeof(int32_t), stream));
+    hipLaunchKernelGGL(sq_mirror1_gen, dim3(aux_blocks), dim3(kBlock), 0, stream, S, F, W);
+    SQ_HIP(hipGetLastError());
+    if (launch_trace(1, 0)) return 1;
+    hipLaunchKernelGGL(sq_mirror1_store, dim3(aux_blocks), dim3(kBlock), 0, stream, W);
+    SQ_HIP(hipGetLastError());
     for (int k0 = 0; k0 < F.samples; k0 += batch) {
         const int kc = std::min(batch, F.samples - k0);
         SQ_HIP(hipMemsetAsync(W.head[0], 0, 32 * sizeof(int32_t), stream));     // both dequeue cursors
         hipLaunchKernelGGL(sq_gen_bounce1, dim3(aux_blocks), dim3(kBlock), 0, stream, S, F, W, k0, kc);
         SQ_HIP(hipGetLastError());
         for (int level = 0; level < 2; ++level) {
-            TraceArgs A{ W.org, W.dir, W.hit, W.n_active, kc, W.head[level], n_lds, stack_cap, (int32_t)s->opt_straggler, W.stats };
-            if (timed([&] {
-                    void* kargs[] = { (void*)&S, (void*)&A };
-                    (void)hipLaunchKernel(trace_fn, dim3(trace_blocks), dim3(trace_threads), kargs, tr_lds, stream);
-                }, "sq_trace_rays")) return 1;
+            if (launch_trace(kc, level)) return 1;
             if (level == 0) hipLaunchKernelGGL(sq_shade1, dim3(aux_blocks), dim3(kBlock), 0, stream, S, F, W, kc);
             else hipLaunchKernelGGL(sq_shade2, dim3(aux_blocks), dim3(kBlock), 0, stream, S, F, W, kc);
             SQ_HIP(hipGetLastError());

@@ -129,21 +129,26 @@ __device__ __forceinline__ Surface surface_of(const SceneView& S, int tri) {
     return s;
 }
 
-// bounceRay (src/Lib.hs:155-181): x and u are the SAME draw nu (same `gen`); v is the next draw nv.
-__device__ __forceinline__ f3 bounce_dir(f3 d, const Surface& s, uint32_t nu, uint32_t nv) {
-    const float x = sq::unit_float(nu);
-    if (s.reflective < x) {                                             // scatterRay, src/Lib.hs:166-172
-        const float u = x, v = sq::unit_float(nv);
-        const float th = 2 * sq::kPi * u;
-        const float ph = sq::facos(2 * v - 1);
-        float sth, cth, sph, cph;
-        sq::fsincos(th, sth, cth); sq::fsincos(ph, sph, cph);
-        const f3 nd = sq::mk(cth * sph, sth * sph, cph);                // randomVector, src/Lib.hs:192-198
-        const float old_ = sq::hsignum(sq::dot(d, s.n)), new_ = sq::hsignum(sq::dot(nd, s.n));
-        return (old_ == new_) ? -nd : nd;
-    }
-    const f3 dn = sq::normalize(s.n);                                   // reflectRay, src/Lib.hs:176-181
+// bounceRay (src/Lib.hs:155-160): `ref < x` scatters, otherwise mirrors; x is the first draw of `gen`.
+__device__ __forceinline__ bool scatters(const Surface& s, uint32_t nu) { return s.reflective < sq::unit_float(nu); }
+// scatterRay (src/Lib.hs:166-172): u is the SAME draw nu as x (same `gen`); v is the next draw nv.
+__device__ __forceinline__ f3 scatter_dir(f3 d, const Surface& s, uint32_t nu, uint32_t nv) {
+    const float u = sq::unit_float(nu), v = sq::unit_float(nv);
+    const float th = 2 * sq::kPi * u;
+    const float ph = sq::facos(2 * v - 1);
+    float sth, cth, sph, cph;
+    sq::fsincos(th, sth, cth); sq::fsincos(ph, sph, cph);
+    const f3 nd = sq::mk(cth * sph, sth * sph, cph);                    // randomVector, src/Lib.hs:192-198
+    const float old_ = sq::hsignum(sq::dot(d, s.n)), new_ = sq::hsignum(sq::dot(nd, s.n));
+    return (old_ == new_) ? -nd : nd;
+}
+// reflectRay (src/Lib.hs:176-181): no random input, so it is the same ray for every sample that mirrors.
+__device__ __forceinline__ f3 mirror_dir(f3 d, const Surface& s) {
+    const f3 dn = sq::normalize(s.n);
     return d - sq::scale(2 * sq::dot(dn, d), dn);
+}
+__device__ __forceinline__ f3 bounce_dir(f3 d, const Surface& s, uint32_t nu, uint32_t nv) {
+    return scatters(s, nu) ? scatter_dir(d, s, nu, nv) : mirror_dir(d, s);
 }
 
 // rgbFloatToPixelRGB (src/Lib.hs:93-104).  floor :: Float -> Word8 wraps mod 256 and maps NaN/Inf to 0.
