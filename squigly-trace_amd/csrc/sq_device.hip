@@ -272,6 +272,27 @@ __global__ void __launch_bounds__(kBlock) sq_shade1(const SceneView S, const Fra
         const f3 p1 = sq::mk(org.x, org.y, org.z) + sq::scale(__int_as_float(hit.x), d1);
         const uint2 r = W.rng12[sid];
         const f3 d2 = bounce_dir(d1, s1, r.x, r.y);                     // gen advanced by one: x = u = p(n1), v = p(n2)
+        // Ray 2 is the last one: all it contributes is L2 = s2*0 + e2, the emission of whatever it hits
+        // (src/Lib.hs:129,135-137).  Whatever the traversal returns is a triangle that mollerTrumbore accepted
+        // for this very ray, so if the SAME function rejects every emissive triangle, the result is a
+        // non-emissive hit or a miss, and L2 is exactly (+0,+0,+0) either way (materials are finite).
+        // Only rays that could reach an emitter are traced.
+        if (S.n_emitters >= 0) {
+            bool may_reach = false;
+            for (int j = 0; j < S.n_emitters && !may_reach; ++j) {
+                const int et = S.emitters[j];
+                const float4 ta = S.tris[3 * et], tb = S.tris[3 * et + 1], tc = S.tris[3 * et + 2];
+                float t_unused;
+                may_reach = moller_trumbore(p1, d2, sq::mk(ta.x, ta.y, ta.z), sq::mk(tb.x, tb.y, tb.z), sq::mk(tc.x, tc.y, tc.z), t_unused);
+            }
+            if (!may_reach) {
+                const Surface s0 = surface_of(S, W.px_tri0[sid % A]);
+                const f3 L1 = s1.surf * sq::mk(0, 0, 0) + s1.emit;
+                store_rad(W, sid, s0.surf * L1 + s0.emit);
+                W.org[sid].w = kDead;
+                continue;
+            }
+        }
         W.org[sid] = make_float4(p1.x, p1.y, p1.z, kLive);
         W.dir[sid] = make_float4(d2.x, d2.y, d2.z, __int_as_float(tri1));
     }
@@ -484,7 +505,7 @@ __global__ void sq_debug_kernel(int op, const void* a, const void* b, long long 
 struct sq_device_scene {
     int device = 0;
     SceneView view{};
-    void *d_branches = nullptr, *d_leaves = nullptr, *d_tris = nullptr, *d_mats = nullptr, *d_verts = nullptr, *d_trix = nullptr, *d_rbranch = nullptr;
+    void *d_branches = nullptr, *d_leaves = nullptr, *d_tris = nullptr, *d_mats = nullptr, *d_verts = nullptr, *d_trix = nullptr, *d_rbranch = nullptr, *d_emitters = nullptr;
     int height = 0; bool small_index = false; int n_cu = 256;
     // workspace (grow-only)
     Work work{}; void* d_work = nullptr; size_t work_bytes = 0; int64_t work_pixels = 0, work_slots = 0;
@@ -651,6 +672,21 @@ extern "C" int sq_scene_upload(const sq_scene* sc, int32_t device, sq_device_sce
             rroot = enc(ref[0]);
         } else { trix.clear(); }
     }
+    // Emissive triangles (for the last-bounce shortcut of sq_shade1).  Disabled (-1) when a material value is not
+    // finite (then s*0 + e is not exactly +0 for non-emitters) or when the list is long enough to cost more than it saves.
+    std::vector<int32_t> emitters; int32_t n_emitters = -1;
+    {
+        bool finite = true;
+        std::vector<char> emits((size_t)sc->n_mats, 0);
+        for (int32_t i = 0; i < sc->n_mats; ++i) {
+            const sq_material& m = sc->mats[i];
+            const float comp[8] = { m.reflective, m.surf[0], m.surf[1], m.surf[2], m.emissive, m.emit[0], m.emit[1], m.emit[2] };
+            for (float c : comp) if (!(c - c == 0.0f)) finite = false;
+            for (int k = 0; k < 3; ++k) { const float e = m.emissive * m.emit[k]; uint32_t bits; std::memcpy(&bits, &e, 4); if (bits != 0u) emits[(size_t)i] = 1; }
+        }
+        for (int32_t i = 0; i < sc->n_tris; ++i) if (emits[(size_t)sc->tris[i].mat]) emitters.push_back(i);
+        if (finite && emitters.size() <= 64) n_emitters = (int32_t)emitters.size();
+    }
     SQ_HIP(hipSetDevice(device));
     sq_device_scene* s = new sq_device_scene;
     s->device = device; s->height = height;
@@ -665,7 +701,8 @@ extern "C" int sq_scene_upload(const sq_scene* sc, int32_t device, sq_device_sce
     if (up(&s->d_branches, br.data(), br.size() * sizeof(DevBranch)) || up(&s->d_leaves, lf.data(), lf.size() * sizeof(DevLeaf)) ||
         up(&s->d_tris, tr.data(), tr.size() * sizeof(DevTri)) || up(&s->d_mats, mt.data(), mt.size() * sizeof(DevMat)) ||
         up(&s->d_verts, uverts.data(), uverts.size() * sizeof(float)) || up(&s->d_trix, trix.data(), trix.size() * sizeof(uint16_t)) ||
-        up(&s->d_rbranch, rbranch.data(), rbranch.size() * sizeof(uint32_t))) {
+        up(&s->d_rbranch, rbranch.data(), rbranch.size() * sizeof(uint32_t)) ||
+        up(&s->d_emitters, emitters.data(), emitters.size() * sizeof(int32_t))) {
         sq_scene_free(s);
         return 1;
     }
@@ -678,6 +715,7 @@ extern "C" int sq_scene_upload(const sq_scene* sc, int32_t device, sq_device_sce
     v.height = height; v.nonneg_materials = nonneg ? 1 : 0;
     v.verts4 = (const float4*)s->d_verts; v.trix = trix.empty() ? nullptr : (const ushort4*)s->d_trix; v.n_verts = (int32_t)(uverts.size() / 4);
     v.rbranch = (const uint32_t*)s->d_rbranch; v.rroot = rroot;
+    v.emitters = (const int32_t*)s->d_emitters; v.n_emitters = n_emitters;
     *out = s;
     return 0;
 }
@@ -686,7 +724,7 @@ extern "C" void sq_scene_free(sq_device_scene* s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
     for (auto& p : s->pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
-    (void)hipFree(s->d_branches); (void)hipFree(s->d_leaves); (void)hipFree(s->d_tris); (void)hipFree(s->d_mats); (void)hipFree(s->d_verts); (void)hipFree(s->d_trix); (void)hipFree(s->d_rbranch);
+    (void)hipFree(s->d_branches); (void)hipFree(s->d_leaves); (void)hipFree(s->d_tris); (void)hipFree(s->d_mats); (void)hipFree(s->d_verts); (void)hipFree(s->d_trix); (void)hipFree(s->d_rbranch); (void)hipFree(s->d_emitters);
     (void)hipFree(s->d_work);
     delete s;
 }

@@ -51,6 +51,8 @@ struct SceneView {
     int32_t n_verts;
     int32_t height;           // BIH.height; a traversal never holds more than height-1 frames
     int32_t nonneg_materials; // 1 if every material component is >= +0 (enables the exact s == 0 shortcuts)
+    const int32_t* emitters;  // triangles whose emission `emissive *^ emitColor` is not exactly (+0,+0,+0)
+    int32_t n_emitters;       // their number, or -1 when the last-bounce shortcut is disabled (see sq_shade1)
 };
 
 struct Hit { float t; int32_t tri; };   // tri < 0 : Nothing.  dist is derived from t on demand (hit_dist)
