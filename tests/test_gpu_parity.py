@@ -344,3 +344,38 @@ def test_config_c4_shard_of_eight(sqt, product_scene, oracle_scene, dev):
         o, o8, _ = ob.render(ocam, n, w, h, threads=THREADS, rows=(y, y + 1))
         assert np.array_equal(bits(avg[j:j + 1].cpu().numpy()), bits(o)), y
         assert np.array_equal(rgb[j:j + 1].cpu().numpy(), o8)
+
+
+@pytest.mark.parametrize("seed,n_emit", [(1, 3), (2, 0), (3, 70), (4, 12)])
+def test_random_soups_with_mirrors_and_emitters(sqt, O, seed, n_emit):
+    """Random triangle soups with diffuse, half-mirror, full-mirror and emissive triangles: exercises the
+    once-per-pixel mirror ray, the last-bounce emitter test (few emitters), its off switch (70 > 64 emitters),
+    a scene without emitters, occluded emitters, and COMBINE frames on overlapping geometry."""
+    rng = np.random.default_rng(seed)
+    n = 400
+    c = rng.uniform(-1.5, 1.5, (n, 1, 3))
+    v = (c + rng.normal(0, 0.35, (n, 3, 3))).astype(np.float32)
+    mats = np.zeros(4, sqt._native.MAT_DTYPE)
+    mats["reflective"] = [0.0, 0.5, 1.0, 0.0]
+    mats["surf"] = [[0.7, 0.6, 0.5], [0.4, 0.8, 0.6], [0.9, 0.9, 0.9], [0.0, 0.0, 0.0]]
+    mats["emissive"] = [0, 0, 0, 25]
+    mats["emit"] = [[0, 0, 0], [0, 0, 0], [0, 0, 0], [1.0, 0.8, 0.6]]
+    mat = rng.integers(0, 3, n)
+    mat[rng.choice(n, n_emit, replace=False)] = 3
+    tris = np.zeros(n, sqt._native.TRI_DTYPE)
+    tris["v0"], tris["v1"], tris["v2"], tris["mat"] = v[:, 0], v[:, 1], v[:, 2], mat
+    bih = sqt.BIH(sqt.Mesh.from_arrays(tris, mats))
+    ot = np.zeros(n, O.TRI_DTYPE)
+    ot["a"], ot["b"], ot["c"] = v[:, 0], v[:, 1], v[:, 2]
+    for f in ("reflective", "surf", "emissive", "emit"):
+        ot[f] = mats[f][mat]
+    ob = O.BIH(ot)
+    cam_txt = b"-6 0.1 0.2\n0 0 0\n"
+    cam_p, cam_o = sqt.camera_from_text(cam_txt), O.camera_from_text(cam_txt)
+    w, h, spp = 40, 40, 48
+    g = sqt.render_f32(bih, cam_p, spp, (w, h))
+    o, _, cnt = ob.render(cam_o, spp, w, h, threads=THREADS)
+    assert np.array_equal(bits(g), bits(o)), int((bits(g) != bits(o)).any(-1).sum())
+    assert cnt["b_rays"] > 20000
+    if n_emit:
+        assert (g > 0).any()
