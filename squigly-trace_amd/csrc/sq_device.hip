@@ -53,6 +53,12 @@ struct Frame {
     int32_t row_block, shard, n_shards, local_rows;
     float* out_avg; uint8_t* out_rgb;
 };
+__device__ __forceinline__ void pixel_coords(const Frame& F, int pix, int& y, int& x) {   // 32-bit: cheap div/mod
+    const int j = pix / F.h;
+    x = pix - j * F.h;
+    const int blk = j / F.row_block;
+    y = (blk * F.n_shards + F.shard) * F.row_block + (j - blk * F.row_block);
+}
 __device__ __forceinline__ void pixel_coords(const Frame& F, long long pix, int& y, int& x) {
     const int j = (int)(pix / F.h);
     x = (int)(pix - (long long)j * F.h);
@@ -172,7 +178,7 @@ __global__ void __launch_bounds__(kBlock) sq_primary(const SceneView S, const Fr
 struct Pixel0 { f3 p0, d0; Surface s0; int y, x; };
 __device__ __forceinline__ Pixel0 load_pixel0(const SceneView& S, const Frame& F, const Work& W, int a) {
     Pixel0 P;
-    pixel_coords(F, W.px_pixel[a], P.y, P.x);
+    pixel_coords(F, (int)W.px_pixel[a], P.y, P.x);
     P.d0 = primary_dir(F.cam_rot, F.w, F.h, P.y, P.x);
     P.p0 = sq::mk(F.cam_pos[0], F.cam_pos[1], F.cam_pos[2]) + sq::scale(W.px_t0[a], P.d0);   // intersectPoint, src/Geometry.hs:134
     P.s0 = surface_of(S, W.px_tri0[a]);
@@ -191,9 +197,9 @@ __device__ __forceinline__ void store_rad(const Work& W, long long sid, f3 L) {
 // Depth-0 bounce of every sample of the batch: RNG, bounceRay, ray 1 into slot sid (src/Lib.hs:133-134).
 __global__ void __launch_bounds__(kBlock) sq_gen_bounce1(const SceneView S, const Frame F, const Work W, int k_base, int k_count) {
     const int A = *W.n_active;
-    const long long total = (long long)A * k_count;
-    for (long long sid = (long long)blockIdx.x * kBlock + threadIdx.x; sid < total; sid += (long long)gridDim.x * kBlock) {
-        const int a = (int)(sid % A), k = k_base + (int)(sid / A);
+    const unsigned total = (unsigned)A * (unsigned)k_count;             // <= slots <= 2^29: 32-bit index arithmetic
+    for (unsigned sid = blockIdx.x * kBlock + threadIdx.x; sid < total; sid += gridDim.x * kBlock) {
+        const int kl = (int)(sid / (unsigned)A), a = (int)(sid - (unsigned)kl * (unsigned)A), k = k_base + kl;
         const Pixel0 P = load_pixel0(S, F, W, a);
         if (absorbs(S, P.s0)) {
             store_rad(W, sid, P.s0.surf * sq::mk(0, 0, 0) + P.s0.emit);
@@ -238,14 +244,14 @@ __global__ void __launch_bounds__(kBlock) sq_mirror1_store(const Work W) {
 // After ray 1: a miss finishes the sample; a hit either finishes it (absorbing surface) or puts ray 2 in the slot.
 __global__ void __launch_bounds__(kBlock) sq_shade1(const SceneView S, const Frame F, const Work W, int k_count) {
     const int A = *W.n_active;
-    const long long total = (long long)A * k_count;
-    for (long long sid = (long long)blockIdx.x * kBlock + threadIdx.x; sid < total; sid += (long long)gridDim.x * kBlock) {
+    const unsigned total = (unsigned)A * (unsigned)k_count;
+    for (unsigned sid = blockIdx.x * kBlock + threadIdx.x; sid < total; sid += gridDim.x * kBlock) {
         const float4 org = W.org[sid];
         if (org.w == kDead) continue;
         const bool mirrored = (org.w == kMirror);
         int2 hit; f3 d1;
         if (mirrored) {                                                 // the pixel's mirror ray and its hit
-            const int a = (int)(sid % A);
+            const int a = (int)(sid % (unsigned)A);
             const Pixel0 P = load_pixel0(S, F, W, a);
             d1 = mirror_dir(P.d0, P.s0);
             hit = make_int2(__float_as_int(W.px_mt[a]), W.px_mtri[a]);
@@ -256,14 +262,14 @@ __global__ void __launch_bounds__(kBlock) sq_shade1(const SceneView S, const Fra
         }
         const int tri1 = hit.y;
         if (tri1 < 0) {                                                 // raytrace ... 1 = black
-            const Surface s0 = surface_of(S, W.px_tri0[sid % A]);
+            const Surface s0 = surface_of(S, W.px_tri0[sid % (unsigned)A]);
             store_rad(W, sid, s0.surf * sq::mk(0, 0, 0) + s0.emit);
             W.org[sid].w = kDead;
             continue;
         }
         const Surface s1 = surface_of(S, tri1);
         if (absorbs(S, s1)) {
-            const Surface s0 = surface_of(S, W.px_tri0[sid % A]);
+            const Surface s0 = surface_of(S, W.px_tri0[sid % (unsigned)A]);
             const f3 L1 = s1.surf * sq::mk(0, 0, 0) + s1.emit;
             store_rad(W, sid, s0.surf * L1 + s0.emit);
             W.org[sid].w = kDead;
@@ -286,7 +292,7 @@ __global__ void __launch_bounds__(kBlock) sq_shade1(const SceneView S, const Fra
                 may_reach = moller_trumbore(p1, d2, sq::mk(ta.x, ta.y, ta.z), sq::mk(tb.x, tb.y, tb.z), sq::mk(tc.x, tc.y, tc.z), t_unused);
             }
             if (!may_reach) {
-                const Surface s0 = surface_of(S, W.px_tri0[sid % A]);
+                const Surface s0 = surface_of(S, W.px_tri0[sid % (unsigned)A]);
                 const f3 L1 = s1.surf * sq::mk(0, 0, 0) + s1.emit;
                 store_rad(W, sid, s0.surf * L1 + s0.emit);
                 W.org[sid].w = kDead;
@@ -301,13 +307,13 @@ __global__ void __launch_bounds__(kBlock) sq_shade1(const SceneView S, const Fra
 // After ray 2: L2 = s2*0 + e2 (or black), L1 = s1*L2 + e1, L0 = s0*L1 + e0   (src/Lib.hs:135-137)
 __global__ void __launch_bounds__(kBlock) sq_shade2(const SceneView S, const Frame F, const Work W, int k_count) {
     const int A = *W.n_active;
-    const long long total = (long long)A * k_count;
-    for (long long sid = (long long)blockIdx.x * kBlock + threadIdx.x; sid < total; sid += (long long)gridDim.x * kBlock) {
+    const unsigned total = (unsigned)A * (unsigned)k_count;
+    for (unsigned sid = blockIdx.x * kBlock + threadIdx.x; sid < total; sid += gridDim.x * kBlock) {
         if (W.org[sid].w < 0) continue;
         const int tri1 = __float_as_int(W.dir[sid].w), tri2 = W.hit[sid].y;
         f3 L2 = sq::mk(0, 0, 0);
         if (tri2 >= 0) { const Surface s2 = surface_of(S, tri2); L2 = s2.surf * sq::mk(0, 0, 0) + s2.emit; }
-        const Surface s1 = surface_of(S, tri1), s0 = surface_of(S, W.px_tri0[sid % A]);
+        const Surface s1 = surface_of(S, tri1), s0 = surface_of(S, W.px_tri0[sid % (unsigned)A]);
         const f3 L1 = s1.surf * L2 + s1.emit;
         store_rad(W, sid, s0.surf * L1 + s0.emit);
     }
