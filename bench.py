@@ -88,6 +88,7 @@ def main():
     bih = sqt.BIH(sqt.Mesh.from_obj(os.path.join(data, "scene.obj"), data))
     cam = sqt.load_camera(os.path.join(data, "camera"))
     scene = sqt.DeviceScene(bih, local_rank)                 # resident in HBM before the timed region
+    scene.enable_timing()                                    # hipEvents around every sq_trace_rays launch, on its stream
     w, h = args.width, args.height
     spp = args.spp * world                                   # weak scaling: 256 spp of work per GPU
 

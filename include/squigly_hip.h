@@ -90,7 +90,7 @@ int  sq_get_stats(sq_device_scene* s, uint64_t* out, int32_t n, int32_t reset);
  *   "lds_node_kb"        streaming form: KB of LDS for the top of the tree (default 32)
  *   "straggler_lanes"    lanes still traversing when a wave turns to its leaves (default 6)
  *   "trace_blocks_per_cu" streaming form: workgroups per CU (0 = as many as LDS allows, up to 4)
- *   "timing"             1 = bracket the dominant kernel with hipEvents (default)
+ *   "timing"             1 = bracket the dominant kernel with hipEvents for sq_kernel_timing (default 0)
  *   "profile"            1 = lane-occupancy counters in sq_get_stats (slower) */
 int  sq_set_option(sq_device_scene* s, const char* key, int64_t value);
 

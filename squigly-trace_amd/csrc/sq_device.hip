@@ -519,7 +519,7 @@ struct sq_device_scene {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
     double total_ms = 0; int64_t launches = 0;
     // options
-    int64_t opt_timing = 1, opt_variant = 2, opt_slots = 48ll << 20, opt_straggler = 6, opt_trace_blocks_per_cu = 0, opt_resident = 1, opt_profile = 0, opt_lds_node_kb = 32;
+    int64_t opt_timing = 0, opt_variant = 2, opt_slots = 48ll << 20, opt_straggler = 6, opt_trace_blocks_per_cu = 0, opt_resident = 1, opt_profile = 0, opt_lds_node_kb = 32;
     const char* last_kernel = "sq_trace_rays";
 };
 
@@ -795,7 +795,10 @@ int launch_frame(sq_device_scene* s, const Frame& F, hipStream_t stream) {
         if (s->opt_timing) { SQ_HIP(hipEventCreate(&e0)); SQ_HIP(hipEventCreate(&e1)); SQ_HIP(hipEventRecord(e0, stream)); }
         fn();
         SQ_HIP(hipGetLastError());
-        if (s->opt_timing) { SQ_HIP(hipEventRecord(e1, stream)); s->pending.emplace_back(e0, e1); s->last_kernel = name; }
+        if (s->opt_timing) {
+            SQ_HIP(hipEventRecord(e1, stream)); s->pending.emplace_back(e0, e1); s->last_kernel = name;
+            if (s->pending.size() > 8192) SQ_HIP(sq_kernel_timing(s, nullptr, nullptr, nullptr) ? hipErrorUnknown : hipSuccess);   // fold, bounded memory
+        }
         return 0;
     };
     if (s->opt_variant == 1 || F.cast) {

@@ -47,6 +47,10 @@ class DeviceScene:
             C.c_void_p(st.cuda_stream)))
         return out_avg, out_rgb
 
+    def enable_timing(self, on=True):
+        """Bracket every launch of the dominant kernel with hipEvents (read back by kernel_timing)."""
+        self.set_option("timing", int(bool(on)))
+
     def kernel_timing(self):
         """(average ms per launch of the dominant kernel, launches, kernel name) since the last reset."""
         ms, n, name = C.c_double(), C.c_int64(), C.c_char_p()

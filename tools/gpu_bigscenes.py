@@ -12,7 +12,7 @@ if which in ("both", "hf708"): cases.append(("heightfield708 (1002540 tris)", G.
 for name, (obj, sq, camt), (w, h, n) in cases:
     t = time.time(); bih = sqt.BIH(sqt.Mesh.from_text(obj, sq)); tb = time.time() - t
     cam = sqt.camera_from_text(camt)
-    ds = sqt.DeviceScene(bih, 0)
+    ds = sqt.DeviceScene(bih, 0); ds.enable_timing()
     sweep = [(kb, bpc) for kb in (64, 32, 16, 8, 4, 0) for bpc in (0,)] if "sweep" in sys.argv else [(None, None)]
     for kb, bpc in sweep:
         if kb is not None:

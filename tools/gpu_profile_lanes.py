@@ -6,7 +6,7 @@ sqt = importlib.import_module("squigly-trace_amd")
 import torch
 data = os.path.join(ROOT, "data")
 bih = sqt.BIH(sqt.Mesh.from_obj(os.path.join(data, "scene.obj"), data)); cam = sqt.load_camera(os.path.join(data, "camera"))
-ds = sqt.DeviceScene(bih, 0)
+ds = sqt.DeviceScene(bih, 0); ds.enable_timing()
 w, h, n = 1920, 1080, 64
 for res in (1, 0):
     for strag in (6,):

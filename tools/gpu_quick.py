@@ -14,7 +14,7 @@ cam = sqt.load_camera(os.path.join(data, "camera"))
 ob = O.BIH(O.tris_from_obj(os.path.join(data, "scene.obj"), data))
 oc = O.load_camera(os.path.join(data, "camera"))
 ok = True
-ds = sqt.DeviceScene(bih, 0)
+ds = sqt.DeviceScene(bih, 0); ds.enable_timing()
 for (w, h, n, cast) in [(64, 64, 4, False), (48, 80, 3, False), (64, 64, 2, True), (96, 96, 16, False), (200, 120, 33, False)]:
     o_avg, o_rgb, _ = ob.render(oc, n, w, h, cast=cast, threads=16)
     for variant in (1, 2):

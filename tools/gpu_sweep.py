@@ -8,7 +8,7 @@ import torch
 data = os.path.join(ROOT, "data")
 bih = sqt.BIH(sqt.Mesh.from_obj(os.path.join(data, "scene.obj"), data)); cam = sqt.load_camera(os.path.join(data, "camera"))
 ob = O.BIH(O.tris_from_obj(os.path.join(data, "scene.obj"), data)); oc = O.load_camera(os.path.join(data, "camera"))
-ds = sqt.DeviceScene(bih, 0)
+ds = sqt.DeviceScene(bih, 0); ds.enable_timing()
 ok = True
 for (w, h, n) in [(96, 96, 16), (200, 120, 33)]:
     o_avg, _, _ = ob.render(oc, n, w, h, threads=16)
