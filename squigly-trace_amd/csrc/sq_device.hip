@@ -287,9 +287,9 @@ __global__ void __launch_bounds__(kBlock) sq_shade1(const SceneView S, const Fra
             bool may_reach = false;
             for (int j = 0; j < S.n_emitters && !may_reach; ++j) {
                 const int et = S.emitters[j];
-                const float4 ta = S.tris[3 * et], tb = S.tris[3 * et + 1], tc = S.tris[3 * et + 2];
+                const float* tp = S.tris + 9 * (size_t)et;
                 float t_unused;
-                may_reach = moller_trumbore(p1, d2, sq::mk(ta.x, ta.y, ta.z), sq::mk(tb.x, tb.y, tb.z), sq::mk(tc.x, tc.y, tc.z), t_unused);
+                may_reach = moller_trumbore(p1, d2, sq::mk(tp[0], tp[1], tp[2]), sq::mk(tp[3], tp[4], tp[5]), sq::mk(tp[6], tp[7], tp[8]), t_unused);
             }
             if (!may_reach) {
                 const Surface s0 = surface_of(S, W.px_tri0[sid % (unsigned)A]);
@@ -511,7 +511,7 @@ __global__ void sq_debug_kernel(int op, const void* a, const void* b, long long 
 struct sq_device_scene {
     int device = 0;
     SceneView view{};
-    void *d_branches = nullptr, *d_leaves = nullptr, *d_tris = nullptr, *d_mats = nullptr, *d_verts = nullptr, *d_trix = nullptr, *d_rbranch = nullptr, *d_emitters = nullptr;
+    void *d_branches = nullptr, *d_leaves = nullptr, *d_tris = nullptr, *d_mats = nullptr, *d_verts = nullptr, *d_trix = nullptr, *d_rbranch = nullptr, *d_emitters = nullptr, *d_tri_mat = nullptr;
     int height = 0; bool small_index = false; int n_cu = 256;
     // workspace (grow-only)
     Work work{}; void* d_work = nullptr; size_t work_bytes = 0; int64_t work_pixels = 0, work_slots = 0;
@@ -614,11 +614,11 @@ extern "C" int sq_scene_upload(const sq_scene* sc, int32_t device, sq_device_sce
         l.hi[kind] = nd.lmax; r.lo[kind] = nd.rmin;
         box[(size_t)i + 1] = l; box[(size_t)nd.link] = r;
     }
-    std::vector<DevTri> tr((size_t)sc->n_tris);
+    std::vector<DevTri> tr((size_t)sc->n_tris); std::vector<int32_t> tri_mat((size_t)sc->n_tris);
     for (int32_t i = 0; i < sc->n_tris; ++i) {
         const sq_tri& t = sc->tris[i]; DevTri& d = tr[(size_t)i];
         for (int c = 0; c < 3; ++c) { d.v0[c] = t.v0[c]; d.e1[c] = t.v1[c] - t.v0[c]; d.e2[c] = t.v2[c] - t.v0[c]; }
-        d.mat = t.mat; d.pad1 = d.pad2 = 0;
+        tri_mat[(size_t)i] = t.mat;
     }
     std::vector<DevMat> mt((size_t)sc->n_mats);
     bool nonneg = true;
@@ -705,7 +705,7 @@ extern "C" int sq_scene_upload(const sq_scene* sc, int32_t device, sq_device_sce
         return 0;
     };
     if (up(&s->d_branches, br.data(), br.size() * sizeof(DevBranch)) || up(&s->d_leaves, lf.data(), lf.size() * sizeof(DevLeaf)) ||
-        up(&s->d_tris, tr.data(), tr.size() * sizeof(DevTri)) || up(&s->d_mats, mt.data(), mt.size() * sizeof(DevMat)) ||
+        up(&s->d_tris, tr.data(), tr.size() * sizeof(DevTri)) || up(&s->d_tri_mat, tri_mat.data(), tri_mat.size() * sizeof(int32_t)) || up(&s->d_mats, mt.data(), mt.size() * sizeof(DevMat)) ||
         up(&s->d_verts, uverts.data(), uverts.size() * sizeof(float)) || up(&s->d_trix, trix.data(), trix.size() * sizeof(uint16_t)) ||
         up(&s->d_rbranch, rbranch.data(), rbranch.size() * sizeof(uint32_t)) ||
         up(&s->d_emitters, emitters.data(), emitters.size() * sizeof(int32_t))) {
@@ -714,7 +714,7 @@ extern "C" int sq_scene_upload(const sq_scene* sc, int32_t device, sq_device_sce
     }
     SceneView& v = s->view;
     v.branches = (const float4*)s->d_branches; v.leaves = (const int2*)s->d_leaves;
-    v.tris = (const float4*)s->d_tris; v.mats = (const float4*)s->d_mats;
+    v.tris = (const float*)s->d_tris; v.tri_mat = (const int32_t*)s->d_tri_mat; v.mats = (const float4*)s->d_mats;
     for (int c = 0; c < 3; ++c) { v.root_lo[c] = sc->root.lo[c]; v.root_hi[c] = sc->root.hi[c]; }
     v.root_ref = ref[0];
     v.n_branches = nb; v.n_leaves = nl; v.n_tris = sc->n_tris; v.n_mats = sc->n_mats;
@@ -730,7 +730,7 @@ extern "C" void sq_scene_free(sq_device_scene* s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
     for (auto& p : s->pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
-    (void)hipFree(s->d_branches); (void)hipFree(s->d_leaves); (void)hipFree(s->d_tris); (void)hipFree(s->d_mats); (void)hipFree(s->d_verts); (void)hipFree(s->d_trix); (void)hipFree(s->d_rbranch); (void)hipFree(s->d_emitters);
+    (void)hipFree(s->d_branches); (void)hipFree(s->d_leaves); (void)hipFree(s->d_tris); (void)hipFree(s->d_mats); (void)hipFree(s->d_verts); (void)hipFree(s->d_trix); (void)hipFree(s->d_rbranch); (void)hipFree(s->d_emitters); (void)hipFree(s->d_tri_mat);
     (void)hipFree(s->d_work);
     delete s;
 }

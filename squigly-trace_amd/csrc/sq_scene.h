@@ -27,17 +27,18 @@ struct DevBranch {          // 48 B, three 16-byte quads
     int32_t axis; uint32_t left, right; int32_t pad;
 };
 struct DevLeaf { int32_t first, count; };
-struct DevTri {             // 48 B: v0 | e1 = v1 - v0 | e2 = v2 - v0 (same rounding as src/Geometry.hs:130-131)
-    float v0[3]; int32_t mat;
-    float e1[3]; float pad1;
-    float e2[3]; float pad2;
+struct DevTri {             // 36 B: v0 | e1 = v1 - v0 | e2 = v2 - v0 (same rounding as src/Geometry.hs:130-131).
+    float v0[3];            // Unpadded on purpose: the streaming kernel is bound by L2/MALL/HBM bytes on large
+    float e1[3];            // scenes; the material index lives in its own array because only shading needs it.
+    float e2[3];
 };
 struct DevMat { float reflective, sr, sg, sb, emissive, er, eg, eb; };   // 32 B
 
 struct SceneView {
     const float4* branches;   // 3 quads per branch
     const int2* leaves;
-    const float4* tris;       // 3 quads per triangle
+    const float* tris;        // 9 floats per triangle (DevTri)
+    const int32_t* tri_mat;   // material index per triangle
     const float4* mats;       // 2 quads per material
     float root_lo[3], root_hi[3];
     uint32_t root_ref;
@@ -121,11 +122,11 @@ struct Surface {            // what shading needs from a hit triangle
     float reflective; f3 surf; f3 emit;   // emit = emissive *^ emitColor (src/Lib.hs:136)
 };
 __device__ __forceinline__ Surface surface_of(const SceneView& S, int tri) {
-    const float4 a = S.tris[3 * tri], b = S.tris[3 * tri + 1], c = S.tris[3 * tri + 2];
-    const int m = __float_as_int(a.w);
+    const float* t = S.tris + 9 * (size_t)tri;
+    const int m = S.tri_mat[tri];
     const float4 m0 = S.mats[2 * m], m1 = S.mats[2 * m + 1];
     Surface s;
-    s.n = sq::cross(sq::mk(b.x, b.y, b.z), sq::mk(c.x, c.y, c.z));
+    s.n = sq::cross(sq::mk(t[3], t[4], t[5]), sq::mk(t[6], t[7], t[8]));
     s.reflective = m0.x; s.surf = sq::mk(m0.y, m0.z, m0.w);
     s.emit = sq::scale(m1.x, sq::mk(m1.y, m1.z, m1.w));
     return s;
@@ -234,18 +235,16 @@ struct ResidentNodes {
 // Triangle sources: (v0, e1, e2) of triangle i.  e1 = v1 - v0 and e2 = v2 - v0 are the reference's
 // edge1/edge2 (src/Geometry.hs:130-131) whether they were subtracted at upload or here.
 struct GlobalTris {
-    const float4* t; const int2* leaves;
-    struct Handle { int i; };
-    struct Raw { float4 a, b, c; };
-    __device__ __forceinline__ Handle handle(int i) const { return Handle{ i }; }
-    __device__ __forceinline__ Raw load(Handle h) const { return Raw{ t[3 * h.i], t[3 * h.i + 1], t[3 * h.i + 2] }; }
-    __device__ __forceinline__ void decode(const Raw& r, f3& v0, f3& e1, f3& e2) const {
-        v0 = sq::mk(r.a.x, r.a.y, r.a.z); e1 = sq::mk(r.b.x, r.b.y, r.b.z); e2 = sq::mk(r.c.x, r.c.y, r.c.z);
+    static constexpr bool kPairLoads = true;
+    const float* t; const int2* leaves;
+    __device__ __forceinline__ void get(int i, f3& v0, f3& e1, f3& e2) const {
+        const float* p = t + 9 * (size_t)i;
+        v0 = sq::mk(p[0], p[1], p[2]); e1 = sq::mk(p[3], p[4], p[5]); e2 = sq::mk(p[6], p[7], p[8]);
     }
-    __device__ __forceinline__ void get(int i, f3& v0, f3& e1, f3& e2) const { decode(load(handle(i)), v0, e1, e2); }
     __device__ __forceinline__ int2 leaf(uint32_t ref) const { return leaves[ref & ~kLeafBit]; }
 };
 struct ResidentTris {           // whole scene resident in LDS: 16-bit indexed triangles + unique vertices (16 B each)
+    static constexpr bool kPairLoads = false;
     const SQ_LDS v4f* verts; const SQ_LDS v4us* trix;
     __device__ __forceinline__ void get(int i, f3& v0, f3& e1, f3& e2) const {
         const v4us r = trix[i];
@@ -321,7 +320,24 @@ template <typename TriSrc>
 __device__ __forceinline__ void trav_leaf(Trav& T, const TriSrc& G) {
     const int2 lf = G.leaf(T.cur);
     T.R.tri = -1;
-    for (int i = lf.x; i < lf.x + lf.y; ++i) {
+    int i = lf.x;
+    const int end = lf.x + lf.y;
+    if constexpr (TriSrc::kPairLoads) {          // from L2/HBM: several triangles' loads in flight per iteration
+        for (; i + 3 < end; i += 4) {
+            f3 a0, a1, a2, b0, b1, b2, c0, c1, c2, d0, d1, d2;
+            G.get(i, a0, a1, a2); G.get(i + 1, b0, b1, b2); G.get(i + 2, c0, c1, c2); G.get(i + 3, d0, d1, d2);
+            leaf_fold(T, a0, a1, a2, i); leaf_fold(T, b0, b1, b2, i + 1);
+            leaf_fold(T, c0, c1, c2, i + 2); leaf_fold(T, d0, d1, d2, i + 3);
+        }
+        for (; i + 1 < end; i += 2) {
+            f3 a0, a1, a2, b0, b1, b2;
+            G.get(i, a0, a1, a2);
+            G.get(i + 1, b0, b1, b2);
+            leaf_fold(T, a0, a1, a2, i);
+            leaf_fold(T, b0, b1, b2, i + 1);
+        }
+    }
+    for (; i < end; ++i) {
         f3 v0, e1, e2;
         G.get(i, v0, e1, e2);
         leaf_fold(T, v0, e1, e2, i);
