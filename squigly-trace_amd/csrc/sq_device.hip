@@ -806,7 +806,8 @@ int launch_frame(sq_device_scene* s, const Frame& F, hipStream_t stream) {
         return timed([&] { hipLaunchKernelGGL(sq_render_pixels<StackT>, dim3((unsigned)px_blocks), dim3(kBlock), px_lds, stream, S, F); }, "sq_render_pixels");
     }
     // ---- wavefront pipeline ----
-    const int64_t slots = std::max<int64_t>(s->opt_slots, pixels);          // at least one sample of every pixel per batch
+    // at least one sample of every pixel per batch, never more slots than the frame has samples
+    const int64_t slots = std::max<int64_t>(pixels, std::min<int64_t>(s->opt_slots, (int64_t)pixels * F.samples));
     if (ensure_workspace(s, pixels, slots)) return 1;
     const Work& W = s->work;
     const int batch = (int)std::max<int64_t>(1, std::min<int64_t>(F.samples, slots / pixels));
