@@ -143,13 +143,21 @@ def test_kernel_variants_agree(sqt, product_scene, oracle_scene, dev, w, h, n, s
     bih, cam, _ = product_scene
     ob, ocam, _ = oracle_scene
     outs = []
-    for variant in (1, 2):
+    # variant 1 = per-pixel kernel; variant 2 = wavefront pipeline with the resident (LDS) or the streaming trace
+    # kernel, with and without the lane-occupancy counters (a separate template instantiation)
+    for variant, resident, profile in ((1, 1, 0), (2, 1, 0), (2, 0, 0), (2, 1, 1), (2, 0, 1)):
         dev.set_option("variant", variant)
+        dev.set_option("resident", resident)
+        dev.set_option("profile", profile)
         dev.set_option("slots", slots)
         a, r = dev.render_rows(cam, n, w, h)
         torch.cuda.synchronize()
         outs.append((a.cpu().numpy(), r.cpu().numpy()))
+    st = dev.stats(reset=True)
+    assert st[0] > 0 and st[5] > 0                      # rays traced, triangle tests counted by the profile build
     dev.set_option("variant", 2)
+    dev.set_option("resident", 1)
+    dev.set_option("profile", 0)
     dev.set_option("slots", 48 << 20)
     o, o8, _ = ob.render(ocam, n, w, h, threads=THREADS)
     for a, r in outs:
