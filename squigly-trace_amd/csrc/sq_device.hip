@@ -519,7 +519,7 @@ struct sq_device_scene {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
     double total_ms = 0; int64_t launches = 0;
     // options
-    int64_t opt_timing = 0, opt_variant = 2, opt_slots = 48ll << 20, opt_straggler = 6, opt_trace_blocks_per_cu = 0, opt_resident = 1, opt_profile = 0, opt_lds_node_kb = 32;
+    int64_t opt_timing = 0, opt_variant = 2, opt_slots = 512ll << 20, opt_straggler = 6, opt_trace_blocks_per_cu = 0, opt_resident = 1, opt_profile = 0, opt_lds_node_kb = 32;
     const char* last_kernel = "sq_trace_rays";
 };
 
@@ -810,7 +810,11 @@ int launch_frame(sq_device_scene* s, const Frame& F, hipStream_t stream) {
     const int64_t slots = std::max<int64_t>(pixels, std::min<int64_t>(s->opt_slots, (int64_t)pixels * F.samples));
     if (ensure_workspace(s, pixels, slots)) return 1;
     const Work& W = s->work;
-    const int batch = (int)std::max<int64_t>(1, std::min<int64_t>(F.samples, slots / pixels));
+    // samples per batch: as many as the workspace holds, split evenly (few large launches: a small trace launch
+    // wastes its ramp-up and drain, and the second-bounce launches only carry a few percent of the slots)
+    const int max_batch = (int)std::max<int64_t>(1, std::min<int64_t>(F.samples, slots / pixels));
+    const int n_batches = (F.samples + max_batch - 1) / max_batch;
+    const int batch = (F.samples + n_batches - 1) / n_batches;
     if (F.out_avg) SQ_HIP(hipMemsetAsync(F.out_avg, 0, (size_t)pixels * 3 * sizeof(float), stream));   // pixels whose primary ray misses: black
     if (F.out_rgb) SQ_HIP(hipMemsetAsync(F.out_rgb, 0, (size_t)pixels * 3, stream));
     SQ_HIP(hipMemsetAsync(W.n_active, 0, 64 * sizeof(int32_t), stream));

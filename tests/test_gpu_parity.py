@@ -158,7 +158,7 @@ def test_kernel_variants_agree(sqt, product_scene, oracle_scene, dev, w, h, n, s
     dev.set_option("variant", 2)
     dev.set_option("resident", 1)
     dev.set_option("profile", 0)
-    dev.set_option("slots", 48 << 20)
+    dev.set_option("slots", 512 << 20)
     o, o8, _ = ob.render(ocam, n, w, h, threads=THREADS)
     for a, r in outs:
         assert np.array_equal(bits(a), bits(o)) and np.array_equal(r, o8)

@@ -27,7 +27,7 @@ for (w, h, n, cast) in [(64, 64, 4, False), (48, 80, 3, False), (64, 64, 2, True
         nd = int((g_avg.view(np.uint32) != o_avg.view(np.uint32)).any(-1).sum())
         print(f"{w}x{h} n={n} cast={cast} variant={variant}: avg bit-equal={same} rgb equal={same8} differing pixels={nd} maxabs={np.abs(g_avg-o_avg).max():.3g}", flush=True)
         ok &= same and same8
-ds.set_option("slots", 48 << 20)
+ds.set_option("slots", 512 << 20)
 args = [a for a in sys.argv[1:]]
 for variant in (1, 2):
     ds.set_option("variant", variant)

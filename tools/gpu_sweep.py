@@ -17,7 +17,7 @@ for (w, h, n) in [(96, 96, 16), (200, 120, 33)]:
         a, _ = ds.render_rows(cam, n, w, h); torch.cuda.synchronize()
         same = np.array_equal(a.cpu().numpy().view(np.uint32), o_avg.view(np.uint32)); ok &= same
         print(f"{w}x{h}@{n} resident={res}: parity={same}", flush=True)
-ds.set_option("slots", 48 << 20)
+ds.set_option("slots", 512 << 20)
 w, h, n = 1920, 1080, 64
 for res in (1, 0):
     ds.set_option("resident", res)
