@@ -145,8 +145,23 @@ constexpr float kPi = 3.14159265358979323846f;   // pi :: Float
 // ---------------- TFGen (tf-random 0.5): first three outputs of mkTFGen seed ----------------
 // Threefish-256 (Skein 1.3), key = (seed,0,0,0), zero tweak, zero counter block; outputs are the
 // low then high halves of the ciphertext words (src/Lib.hs:86,134,185).
-SQ_HD uint64_t rotl64(uint64_t v, int r) { return (v << r) | (v >> (64 - r)); }
-#define SQ_TF_MIX(a, b, r) a += b; b = rotl64(b, r) ^ a
+// 64-bit rotate by a compile-time amount.  On the device it is two v_alignbit_b32 on the register halves
+// (the generic shift/or form compiles to 64-bit shifts, which issue at a quarter of the rate).
+template <int R> SQ_HD uint64_t rotl64c(uint64_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    if (R == 32) return ((uint64_t)lo << 32) | hi;
+    if (R < 32) {
+        const uint32_t nh = __builtin_amdgcn_alignbit(hi, lo, 32 - R), nl = __builtin_amdgcn_alignbit(lo, hi, 32 - R);
+        return ((uint64_t)nh << 32) | nl;
+    }
+    const uint32_t nh = __builtin_amdgcn_alignbit(lo, hi, 64 - R), nl = __builtin_amdgcn_alignbit(hi, lo, 64 - R);
+    return ((uint64_t)nh << 32) | nl;
+#else
+    return (v << R) | (v >> (64 - R));
+#endif
+}
+#define SQ_TF_MIX(a, b, r) a += b; b = rotl64c<r>(b) ^ a
 #define SQ_TF_ROUNDS8(s)                                                              \
     x0 += k[(s) % 5]; x1 += k[((s) + 1) % 5]; x2 += k[((s) + 2) % 5]; x3 += k[((s) + 3) % 5] + (uint64_t)(s); \
     SQ_TF_MIX(x0, x1, 14); SQ_TF_MIX(x2, x3, 16);                                     \
