@@ -753,19 +753,27 @@ extern "C" int32_t sq_shard_global_row(int32_t j, sq_shard sh) {
 namespace {
 
 // Carves the frame workspace out of one allocation (grow-only; allocation happens outside timed steps after warm-up).
+// If the device cannot give `slots` sample slots the request is halved (down to one sample per pixel): the frame
+// then simply runs in more batches.
 int ensure_workspace(sq_device_scene* s, int64_t pixels, int64_t slots) {
     if (pixels <= s->work_pixels && slots <= s->work_slots && s->d_work) return 0;
     pixels = std::max(pixels, s->work_pixels); slots = std::max(slots, s->work_slots);
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    size_t off = 0;
-    auto take = [&](size_t bytes) { size_t o = off; off += al(bytes); return o; };
-    const size_t o_cnt = take(64 * sizeof(int32_t));
-    const size_t o_stats = take(16 * sizeof(unsigned long long));
-    const size_t o_pix = take(pixels * 4), o_t0 = take(pixels * 4), o_tri0 = take(pixels * 4), o_sum = take(pixels * 12);
-    const size_t o_mt = take(pixels * 4), o_mtri = take(pixels * 4);
-    const size_t o_org = take(slots * 16), o_dir = take(slots * 16), o_hit = take(slots * 8), o_rng = take(slots * 8), o_rad = take(slots * 12);
-    if (s->d_work) { (void)hipFree(s->d_work); s->d_work = nullptr; }
-    if (hipMalloc(&s->d_work, off) != hipSuccess) return sq_set_error("hipMalloc(%zu B) for the frame workspace failed", off);
+    if (s->d_work) { (void)hipFree(s->d_work); s->d_work = nullptr; s->work_pixels = s->work_slots = 0; }
+    size_t off = 0, o_cnt = 0, o_stats = 0, o_pix = 0, o_t0 = 0, o_tri0 = 0, o_sum = 0, o_mt = 0, o_mtri = 0, o_org = 0, o_dir = 0, o_hit = 0, o_rng = 0, o_rad = 0;
+    for (;;) {
+        off = 0;
+        auto take = [&](size_t bytes) { size_t o = off; off += al(bytes); return o; };
+        o_cnt = take(64 * sizeof(int32_t)); o_stats = take(16 * sizeof(unsigned long long));
+        o_pix = take(pixels * 4); o_t0 = take(pixels * 4); o_tri0 = take(pixels * 4); o_sum = take(pixels * 12);
+        o_mt = take(pixels * 4); o_mtri = take(pixels * 4);
+        o_org = take(slots * 16); o_dir = take(slots * 16); o_hit = take(slots * 8); o_rng = take(slots * 8); o_rad = take(slots * 12);
+        if (hipMalloc(&s->d_work, off) == hipSuccess) break;
+        (void)hipGetLastError();
+        s->d_work = nullptr;
+        if (slots <= pixels) return sq_set_error("hipMalloc(%zu B) for the frame workspace failed", off);
+        slots = std::max<int64_t>(pixels, slots / 2);
+    }
     char* base = (char*)s->d_work;
     Work& W = s->work;
     int32_t* cnt = (int32_t*)(base + o_cnt);
@@ -810,9 +818,10 @@ int launch_frame(sq_device_scene* s, const Frame& F, hipStream_t stream) {
     const int64_t slots = std::max<int64_t>(pixels, std::min<int64_t>(s->opt_slots, (int64_t)pixels * F.samples));
     if (ensure_workspace(s, pixels, slots)) return 1;
     const Work& W = s->work;
+    const int64_t have_slots = W.slot_capacity;
     // samples per batch: as many as the workspace holds, split evenly (few large launches: a small trace launch
     // wastes its ramp-up and drain, and the second-bounce launches only carry a few percent of the slots)
-    const int max_batch = (int)std::max<int64_t>(1, std::min<int64_t>(F.samples, slots / pixels));
+    const int max_batch = (int)std::max<int64_t>(1, std::min<int64_t>(F.samples, have_slots / pixels));
     const int n_batches = (F.samples + max_batch - 1) / max_batch;
     const int batch = (F.samples + n_batches - 1) / n_batches;
     if (F.out_avg) SQ_HIP(hipMemsetAsync(F.out_avg, 0, (size_t)pixels * 3 * sizeof(float), stream));   // pixels whose primary ray misses: black
