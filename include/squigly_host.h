@@ -33,6 +33,11 @@ void sq_rot_matrix_rads(float alpha, float beta, float gamma, float out9[9]);   
  * The returned object owns the arrays; sq_bih_scene() fills an sq_scene that points into it. */
 typedef struct sq_bih sq_bih;
 int  sq_bih_build(const sq_mesh* mesh, sq_bih** out);
+/* The same build on HIP device `device` (squigly-trace_amd/csrc/sq_bih_device.hip): level-synchronous,
+ * element-parallel, and bit-identical to sq_bih_build -- same split planes (ordered fp32 sums), same stable
+ * partitions, same boxes -- because tree shape and leaf order decide traversal tie-breaks.  Fails (non-zero,
+ * sq_last_error) without a GPU or when a vertex coordinate is not finite; it never falls back to the host. */
+int  sq_bih_build_device(const sq_mesh* mesh, int32_t device, sq_bih** out);
 void sq_bih_scene(const sq_bih* b, sq_scene* out);
 int32_t sq_bih_height(const sq_bih* b);        /* BIH.height       src/BIH.hs:46-48 */
 int32_t sq_bih_num_leaves(const sq_bih* b);    /* BIH.numLeaves    src/BIH.hs:54-56 */

@@ -15,8 +15,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libsquigly_hip.so")
-SOURCES = ["sq_device.hip", "sq_host.cpp"]
-HEADERS = ["sq_math.h", "sq_error.h", "sq_scene.h", "cli_main.cpp", "../../include/squigly_hip.h", "../../include/squigly_host.h"]
+SOURCES = ["sq_device.hip", "sq_bih_device.hip", "sq_host.cpp"]
+HEADERS = ["sq_math.h", "sq_error.h", "sq_scene.h", "sq_host_types.h", "cli_main.cpp", "../../include/squigly_hip.h", "../../include/squigly_host.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
          "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math",
          # v_pk_mul_f32 / v_pk_add_f32 issue at ~9.5 cycles per wave on gfx950 against ~2.6 for the scalar forms

@@ -7,6 +7,7 @@
 // Citations are relative to the reference repository root.
 #include "../../include/squigly_host.h"
 #include "sq_error.h"
+#include "sq_host_types.h"
 #include "sq_math.h"
 
 #include <cstdio>
@@ -16,11 +17,6 @@
 #include <vector>
 
 using sq::f3;
-
-struct sq_mesh {
-    std::vector<sq_tri> tris;
-    std::vector<sq_material> mats;
-};
 
 // ----------------------------------------------------------------------------------------------
 // Text scanning.  The reference grammar is Parsec (src/Obj.hs:96-171); this scanner accepts and
@@ -266,14 +262,6 @@ extern "C" int sq_camera_from_file(const char* path, sq_camera* cam) {
 // ----------------------------------------------------------------------------------------------
 // BIH build (src/BIH.hs:62-99) straight into pre-order arrays.
 // ----------------------------------------------------------------------------------------------
-struct sq_bih {
-    sq_bounds root;
-    std::vector<sq_node> nodes;
-    std::vector<sq_tri> tris;          // leaf order
-    std::vector<sq_material> mats;
-    int32_t height = 0, leaves = 0, longest = 0;
-};
-
 namespace {
 
 struct Builder {

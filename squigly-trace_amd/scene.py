@@ -66,9 +66,13 @@ class Mesh:
 class BIH:
     """BIH.makeBIH result, flattened to the pre-order arrays of include/squigly_hip.h."""
 
-    def __init__(self, mesh: Mesh):
+    def __init__(self, mesh: Mesh, device=None):
+        """device=None: host build (sq_bih_build); device=k: the same tree built on GPU k (sq_bih_build_device)."""
         h = C.c_void_p()
-        N.check(N.lib().sq_bih_build(mesh._h, C.byref(h)))
+        if device is None:
+            N.check(N.lib().sq_bih_build(mesh._h, C.byref(h)))
+        else:
+            N.check(N.lib().sq_bih_build_device(mesh._h, int(device), C.byref(h)))
         self._h = h
         self.scene = N.Scene()
         N.lib().sq_bih_scene(self._h, C.byref(self.scene))
