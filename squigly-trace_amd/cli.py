@@ -10,7 +10,7 @@ import os
 import sys
 import time
 
-from . import BIH, Mesh, Settings, load_camera, render
+from . import BIH, Mesh, Settings, lib, load_camera, render
 
 
 def parse_dimensions(text):
@@ -42,7 +42,8 @@ def main(argv=None):
                         cameraPath=a.camerapath, debug=a.debug, debugPath=a.debugpath, cast=a.cast)
     cam = load_camera(settings.cameraPath)                      # app/Main.hs:38
     mesh = Mesh.from_obj(settings.objPath, "./data")            # loadTris, app/Main.hs:58-61 + src/Obj.hs:52
-    bih = BIH(mesh)                                             # loadBIH, app/Main.hs:63-75
+    # loadBIH, app/Main.hs:63-75.  Both builds give the same arrays; the GPU one wins from a few 10^4 triangles up.
+    bih = BIH(mesh, device=0 if (len(mesh) >= 50000 and lib().sq_device_count() > 0) else None)
     if settings.debug:
         if settings.debugPath:
             nodes = bih.nodes

@@ -15,7 +15,7 @@
 //   * the split plane is a left-to-right fp32 sum.  fp32 addition is not associative, so the sum is a
 //     serial chain by definition: a wave stages 1024 centroids at a time in LDS (coalesced loads, the next
 //     tile in flight) and adds them in order.  The root of a 1M-triangle mesh is one chain of 1M adds
-//     (about 2 ms); every other node of a level runs beside it.
+//     (about 5 ns per add); every other node of a level runs beside it.
 //   * boxes are `foldl1 min` / `foldl1 max` with Haskell's min/max (ties keep the earlier / later operand,
 //     which only shows in the sign of a zero).  They are reduced as 64-bit keys
 //     (order-preserving value bits with -0 == +0) << 32 | (position in the fold), atomicMin / atomicMax after a wave-level
@@ -176,12 +176,27 @@ __global__ void __launch_bounds__(64) k_plane(const int32_t* __restrict__ active
         const int32_t t1 = t0 + kTile;
         if (t1 < n)
             for (int j = 0; j < kPer; ++j) { const int32_t e = t1 + j * 64 + lane; r[j] = e < n ? src[e] : 0.0f; }
-        const int32_t cnt = min(kTile, n - t0);
+        // 32 adds per group, the next group's LDS reads in flight meanwhile (two register sets, no copies).
+        const int groups = (min(kTile, n - t0) + 31) >> 5;
         const float4* q = reinterpret_cast<const float4*>(tile[buf]);
-#pragma unroll 4
-        for (int32_t k = 0; k < (cnt + 3) / 4; ++k) {
-            const float4 v = q[k];
-            sum = sum + v.x; sum = sum + v.y; sum = sum + v.z; sum = sum + v.w;
+        float4 A[8], B[8];
+        auto fetch = [&](float4* dst, int g) {
+            const float4* s = q + min(g, kTile / 32 - 1) * 8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dst[j] = s[j];
+            __builtin_amdgcn_sched_barrier(0);               // keep these reads ahead of the adds that follow
+        };
+        auto fold = [&](const float4* v) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { sum = sum + v[j].x; sum = sum + v[j].y; sum = sum + v[j].z; sum = sum + v[j].w; }
+        };
+        fetch(A, 0);
+        for (int g = 0; g < groups; g += 2) {
+            fetch(B, g + 1);
+            fold(A);
+            if (g + 1 >= groups) break;
+            fetch(A, g + 2);
+            fold(B);
         }
     }
     if (lane == 0) N.plane[node] = sum / (float)min(n, 16777216);
@@ -324,14 +339,13 @@ __global__ void __launch_bounds__(kB) k_gather(int32_t T, const int32_t* __restr
     out[g] = tris[(size_t)ids[i] * kTriFloats + k];
 }
 
-struct DeviceBuffers {
-    std::vector<void*> ptrs;
-    ~DeviceBuffers() { for (void* p : ptrs) (void)hipFree(p); }
-    template <typename T> hipError_t alloc(T** p, size_t n) {
-        void* q = nullptr;
-        hipError_t e = hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T));
-        if (e == hipSuccess) { ptrs.push_back(q); *p = (T*)q; }
-        return e;
+// One allocation carved into 256-byte aligned arrays (two passes: measure, then place).
+struct Arena {
+    char* base = nullptr; size_t used = 0;
+    ~Arena() { if (base) (void)hipFree(base); }
+    template <typename T> void take(T** p, size_t n) {
+        *p = base ? reinterpret_cast<T*>(base + used) : nullptr;
+        used += (std::max<size_t>(n, 1) * sizeof(T) + 255) & ~(size_t)255;
     }
 };
 
@@ -375,26 +389,20 @@ extern "C" int sq_bih_build_device(const sq_mesh* mesh, int32_t device, sq_bih**
 
     const int32_t max_active = T / kLeafLimit + 1;               // disjoint ranges of at least 15 triangles
     const int64_t cap = 2 * (int64_t)T + (int64_t)T / 4 + 16;    // leaves <= T + T/15, branches = leaves - 1
-    DeviceBuffers D;
+    Arena D;
     float *tris, *cen, *out_tris; int32_t *ids[2], *node_of[2], *active[2], *counter; uint32_t *flag, *pos, *scan_tmp; int* bad;
     Nodes N; Keys K;
-    SQ_HIP(D.alloc(&tris, (size_t)T * kTriFloats));
-    SQ_HIP(D.alloc(&out_tris, (size_t)T * kTriFloats));
-    SQ_HIP(D.alloc(&cen, (size_t)T));
-    for (int k = 0; k < 2; ++k) {
-        SQ_HIP(D.alloc(&ids[k], (size_t)T));
-        SQ_HIP(D.alloc(&node_of[k], (size_t)T));
-        SQ_HIP(D.alloc(&active[k], (size_t)max_active));
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass) { const size_t total = D.used; SQ_HIP(hipMalloc((void**)&D.base, total)); D.used = 0; }
+        D.take(&tris, (size_t)T * kTriFloats); D.take(&out_tris, (size_t)T * kTriFloats); D.take(&cen, (size_t)T);
+        for (int k = 0; k < 2; ++k) { D.take(&ids[k], (size_t)T); D.take(&node_of[k], (size_t)T); D.take(&active[k], (size_t)max_active); }
+        D.take(&flag, (size_t)T); D.take(&pos, (size_t)T); D.take(&scan_tmp, (size_t)T / kScanTile + 4096);
+        D.take(&counter, 1); D.take(&bad, 1);
+        D.take(&N.begin, (size_t)cap); D.take(&N.count, (size_t)cap); D.take(&N.axis, (size_t)cap); D.take(&N.left, (size_t)cap);
+        D.take(&N.lmax, (size_t)cap); D.take(&N.rmin, (size_t)cap); D.take(&N.plane, (size_t)cap); D.take(&N.box, (size_t)cap * 6);
+        D.take(&N.state, (size_t)cap);
+        D.take(&K.kmin, (size_t)max_active * 6); D.take(&K.kmax, (size_t)max_active * 6);
     }
-    SQ_HIP(D.alloc(&flag, (size_t)T));
-    SQ_HIP(D.alloc(&pos, (size_t)T));
-    SQ_HIP(D.alloc(&scan_tmp, (size_t)T / kScanTile + 4096));
-    SQ_HIP(D.alloc(&counter, 1));
-    SQ_HIP(D.alloc(&bad, 1));
-    SQ_HIP(D.alloc(&N.begin, (size_t)cap)); SQ_HIP(D.alloc(&N.count, (size_t)cap)); SQ_HIP(D.alloc(&N.axis, (size_t)cap));
-    SQ_HIP(D.alloc(&N.left, (size_t)cap));  SQ_HIP(D.alloc(&N.lmax, (size_t)cap));  SQ_HIP(D.alloc(&N.rmin, (size_t)cap));
-    SQ_HIP(D.alloc(&N.plane, (size_t)cap)); SQ_HIP(D.alloc(&N.box, (size_t)cap * 6)); SQ_HIP(D.alloc(&N.state, (size_t)cap));
-    SQ_HIP(D.alloc(&K.kmin, (size_t)max_active * 6)); SQ_HIP(D.alloc(&K.kmax, (size_t)max_active * 6));
 
     static_assert(sizeof(sq_tri) == kTriFloats * sizeof(float), "sq_tri layout");
     SQ_HIP(hipMemcpy(tris, mesh->tris.data(), (size_t)T * sizeof(sq_tri), hipMemcpyHostToDevice));

@@ -8,6 +8,7 @@ sqt = importlib.import_module("squigly-trace_amd")
 import torch
 torch.cuda.init()
 cases = [("scene.obj", None), ("blob6", G.blob_scene(6)), ("heightfield708", G.heightfield_scene(708))]
+if "only1m" in sys.argv: cases = cases[2:]
 if "big" in sys.argv: cases.append(("heightfield2000", G.heightfield_scene(2000)))
 for name, sc in cases:
     t = time.time()
@@ -18,4 +19,7 @@ for name, sc in cases:
     best = 1e9
     for _ in range(3):
         t = time.time(); dev = sqt.BIH(mesh, device=0); best = min(best, time.time() - t)
-    print(f"{name}: {len(mesh)} tris, load {tl*1e3:.0f} ms, host build {th*1e3:.1f} ms, device build {best*1e3:.1f} ms, height {dev.height}, nodes {dev.scene.n_nodes}", flush=True)
+    t = time.time(); ds = sqt.DeviceScene(dev, 0); torch.cuda.synchronize(); tu = time.time() - t
+    ds.close()
+    print(f"{name}: {len(mesh)} tris, load {tl*1e3:.0f} ms, host build {th*1e3:.1f} ms, device build {best*1e3:.1f} ms, "
+          f"scene upload {tu*1e3:.1f} ms, height {dev.height}, nodes {dev.scene.n_nodes}", flush=True)
