@@ -401,7 +401,7 @@ __global__ void __launch_bounds__(BLOCK) sq_trace_rays(const SceneView S, const 
     } else {
         for (int i = threadIdx.x; i < 3 * A.n_lds; i += BLOCK) { const float4 q = S.branches[i]; lquads[i] = v4f{ q.x, q.y, q.z, q.w }; }
         N = HybridNodes{ lquads, S.branches, (uint32_t)A.n_lds };
-        G = GlobalTris{ S.tris, S.leaves };
+        G = GlobalTris{ S.tris, S.leaves, S.packed_leaves != 0 };
         root_ref = S.root_ref;
     }
     __syncthreads();
@@ -678,6 +678,20 @@ extern "C" int sq_scene_upload(const sq_scene* sc, int32_t device, sq_device_sce
             rroot = enc(ref[0]);
         } else { trix.clear(); }
     }
+    // Streaming form: leaf references carry (first, count) themselves when they fit, which saves the dependent
+    // leaf-table load of every leaf visit.
+    bool packed_leaves = sc->n_tris < (1 << 24);
+    for (int32_t i = 0; i < nl && packed_leaves; ++i) packed_leaves = lf[(size_t)i].count <= 127;
+    uint32_t root_ref = ref[0];
+    if (packed_leaves) {
+        auto enc = [&](uint32_t r) -> uint32_t {
+            if (!(r & kLeafBit)) return r;
+            const DevLeaf& L = lf[r & ~kLeafBit];
+            return kLeafBit | ((uint32_t)L.count << 24) | (uint32_t)L.first;
+        };
+        for (DevBranch& d : br) { d.left = enc(d.left); d.right = enc(d.right); }
+        root_ref = enc(root_ref);
+    }
     // Emissive triangles (for the last-bounce shortcut of sq_shade1).  Disabled (-1) when a material value is not
     // finite (then s*0 + e is not exactly +0 for non-emitters) or when the list is long enough to cost more than it saves.
     std::vector<int32_t> emitters; int32_t n_emitters = -1;
@@ -716,7 +730,7 @@ extern "C" int sq_scene_upload(const sq_scene* sc, int32_t device, sq_device_sce
     v.branches = (const float4*)s->d_branches; v.leaves = (const int2*)s->d_leaves;
     v.tris = (const float*)s->d_tris; v.tri_mat = (const int32_t*)s->d_tri_mat; v.mats = (const float4*)s->d_mats;
     for (int c = 0; c < 3; ++c) { v.root_lo[c] = sc->root.lo[c]; v.root_hi[c] = sc->root.hi[c]; }
-    v.root_ref = ref[0];
+    v.root_ref = root_ref; v.packed_leaves = packed_leaves ? 1 : 0;
     v.n_branches = nb; v.n_leaves = nl; v.n_tris = sc->n_tris; v.n_mats = sc->n_mats;
     v.height = height; v.nonneg_materials = nonneg ? 1 : 0;
     v.verts4 = (const float4*)s->d_verts; v.trix = trix.empty() ? nullptr : (const ushort4*)s->d_trix; v.n_verts = (int32_t)(uverts.size() / 4);

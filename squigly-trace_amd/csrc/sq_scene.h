@@ -42,6 +42,7 @@ struct SceneView {
     const float4* mats;       // 2 quads per material
     float root_lo[3], root_hi[3];
     uint32_t root_ref;
+    int32_t packed_leaves;    // 1: a leaf reference is kLeafBit | count << 24 | first (count <= 127, < 2^24 triangles), no table lookup
     int32_t n_branches, n_leaves, n_tris, n_mats;
     // Resident (LDS) form of the same scene, present when it can be encoded (16-bit vertex indices, leaves
     // of at most 31 triangles, < 2^24 triangles/branches): see "resident encoding" below.
@@ -236,12 +237,15 @@ struct ResidentNodes {
 // edge1/edge2 (src/Geometry.hs:130-131) whether they were subtracted at upload or here.
 struct GlobalTris {
     static constexpr bool kPairLoads = true;
-    const float* t; const int2* leaves;
+    const float* t; const int2* leaves; bool packed;
     __device__ __forceinline__ void get(int i, f3& v0, f3& e1, f3& e2) const {
         const float* p = t + 9 * (size_t)i;
         v0 = sq::mk(p[0], p[1], p[2]); e1 = sq::mk(p[3], p[4], p[5]); e2 = sq::mk(p[6], p[7], p[8]);
     }
-    __device__ __forceinline__ int2 leaf(uint32_t ref) const { return leaves[ref & ~kLeafBit]; }
+    __device__ __forceinline__ int2 leaf(uint32_t ref) const {
+        if (packed) return make_int2((int)(ref & 0xFFFFFFu), (int)((ref >> 24) & 127u));   // saves a dependent load per leaf visit
+        return leaves[ref & ~kLeafBit];
+    }
 };
 struct ResidentTris {           // whole scene resident in LDS: 16-bit indexed triangles + unique vertices (16 B each)
     static constexpr bool kPairLoads = false;
@@ -382,7 +386,7 @@ __device__ __forceinline__ void trav_unwind(Trav& T, const NodeSrc& N, const Tri
 // Whole query, one ray per lane (used where rays of a wave are coherent: primary and shadow rays).
 template <typename NodeSrc, typename StackT>
 __device__ __forceinline__ Hit trace_one(const SceneView& S, const NodeSrc& N, f3 o, f3 d, SQ_LDS StackT* stk, int stride) {
-    const GlobalTris G{ S.tris, S.leaves };
+    const GlobalTris G{ S.tris, S.leaves, S.packed_leaves != 0 };
     Trav T;
     trav_begin(T, S, S.root_ref, o, d);
     while (T.mode != M_DONE) {

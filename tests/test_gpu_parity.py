@@ -91,6 +91,9 @@ def test_small_degenerate_and_empty_scenes(sqt, O):
     scenes = {
         "single-leaf": b"mtllib s.sq\no X\nv -1 0 -1\nv 1 0 -1\nv 0 1 1\nusemtl A\nf 1 2 3\n",
         "twenty-identical": b"mtllib s.sq\no X\nv -1 0 -1\nv 1 0 -1\nv 0 1 1\nusemtl A\n" + b"f 1 2 3\n" * 20,
+        # a terminal leaf longer than a packed leaf reference can describe (127): the leaf-table path of the streaming form
+        "two-hundred-identical": (b"mtllib s.sq\no X\nv -1 0 -1\nv 1 0 -1\nv 0 1 1\nusemtl A\n" + b"f 1 2 3\n" * 200 +
+                                  b"o M\nv -3 -3 -3\nv 3 -3 -3\nv 0 -3 3\nusemtl M\nf 4 5 6\n"),
         "flat-root-box": b"mtllib s.sq\no X\nv -1 0 -1\nv 1 0 -1\nv 0 0 1\nusemtl A\n" + b"f 1 2 3\n" * 20,
         "empty": b"mtllib s.sq\n",
         "mirror-and-light": (b"mtllib s.sq\no L\nv -1 -1 -1\nv 1 -1 -1\nv 0 -1 1\nusemtl A\nf 1 2 3\n"
