@@ -401,7 +401,7 @@ __global__ void __launch_bounds__(BLOCK) sq_trace_rays(const SceneView S, const 
     } else {
         for (int i = threadIdx.x; i < 3 * A.n_lds; i += BLOCK) { const float4 q = S.branches[i]; lquads[i] = v4f{ q.x, q.y, q.z, q.w }; }
         N = HybridNodes{ lquads, S.branches, (uint32_t)A.n_lds };
-        G = GlobalTris{ S.tris, S.leaves, S.packed_leaves != 0 };
+        G = GlobalTris{ S.tris, S.leaves, S.packed_leaves != 0, (size_t)S.n_tris * sizeof(DevTri) > ((size_t)4 << 20) };
         root_ref = S.root_ref;
     }
     __syncthreads();

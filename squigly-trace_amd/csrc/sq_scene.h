@@ -237,7 +237,7 @@ struct ResidentNodes {
 // edge1/edge2 (src/Geometry.hs:130-131) whether they were subtracted at upload or here.
 struct GlobalTris {
     static constexpr bool kPairLoads = true;
-    const float* t; const int2* leaves; bool packed;
+    const float* t; const int2* leaves; bool packed, deep;   // deep: 8 triangles' loads in flight (scene beyond L2)
     __device__ __forceinline__ void get(int i, f3& v0, f3& e1, f3& e2) const {
         const float* p = t + 9 * (size_t)i;
         v0 = sq::mk(p[0], p[1], p[2]); e1 = sq::mk(p[3], p[4], p[5]); e2 = sq::mk(p[6], p[7], p[8]);
@@ -327,6 +327,13 @@ __device__ __forceinline__ void trav_leaf(Trav& T, const TriSrc& G) {
     int i = lf.x;
     const int end = lf.x + lf.y;
     if constexpr (TriSrc::kPairLoads) {          // from L2/HBM: several triangles' loads in flight per iteration
+        if (G.deep) for (; i + 7 < end; i += 8) {
+            f3 v0[8], e1[8], e2[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) G.get(i + k, v0[k], e1[k], e2[k]);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) leaf_fold(T, v0[k], e1[k], e2[k], i + k);
+        }
         for (; i + 3 < end; i += 4) {
             f3 a0, a1, a2, b0, b1, b2, c0, c1, c2, d0, d1, d2;
             G.get(i, a0, a1, a2); G.get(i + 1, b0, b1, b2); G.get(i + 2, c0, c1, c2); G.get(i + 3, d0, d1, d2);
@@ -386,7 +393,7 @@ __device__ __forceinline__ void trav_unwind(Trav& T, const NodeSrc& N, const Tri
 // Whole query, one ray per lane (used where rays of a wave are coherent: primary and shadow rays).
 template <typename NodeSrc, typename StackT>
 __device__ __forceinline__ Hit trace_one(const SceneView& S, const NodeSrc& N, f3 o, f3 d, SQ_LDS StackT* stk, int stride) {
-    const GlobalTris G{ S.tris, S.leaves, S.packed_leaves != 0 };
+    const GlobalTris G{ S.tris, S.leaves, S.packed_leaves != 0, false };
     Trav T;
     trav_begin(T, S, S.root_ref, o, d);
     while (T.mode != M_DONE) {
