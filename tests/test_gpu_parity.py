@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import DATA, GOLDEN
+from conftest import DATA, GOLDEN, ROOT
 
 pytestmark = pytest.mark.gpu
 THREADS = min(os.cpu_count() or 1, 16)
@@ -391,3 +391,13 @@ def test_random_soups_with_mirrors_and_emitters(sqt, O, seed, n_emit):
     assert cnt["b_rays"] > 20000
     if n_emit:
         assert (g > 0).any()
+
+
+def test_randomised_campaign(sqt, O):
+    """A slice of tools/gpu_fuzz.py (random scenes x cameras x frame shapes, both kernel forms, host- and
+    device-built trees): every case bit-equal to the oracle.  The full campaign is run by hand on the GPU box."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gpu_fuzz
+    failures = [(seed, msg) for seed in range(1000, 1400) if (msg := gpu_fuzz.run_case(seed))]
+    assert not failures, failures[:5]

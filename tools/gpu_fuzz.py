@@ -1,0 +1,186 @@
+"""Randomised parity campaign on the GPU box: random scenes x random cameras x random frame shapes, the HIP
+path against the CPU oracle, bit for bit (fp32 `avg` and RGB8).  Prints one line per mismatch with the seed
+that reproduces it, and a summary.  Checker use of the oracle only (like tests/).
+
+    python tools/gpu_fuzz.py [seconds=240] [first_seed=0]
+"""
+import importlib
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import pyoracle as O  # noqa: E402
+
+O.lib()
+sqt = importlib.import_module("squigly-trace_amd")
+sqt.lib()
+import torch  # noqa: E402
+
+THREADS = min(os.cpu_count() or 1, 16)
+
+
+def make_scene(rng):
+    kind = rng.integers(0, 6)
+    scale = float(rng.choice([1e-3, 1.0, 1.0, 1.0, 50.0, 1e4]))
+    if kind == 0:      # soup
+        n = int(rng.choice([1, 2, 14, 15, 16, 40, 200, 1000, 3000]))
+        c = rng.uniform(-2, 2, (n, 1, 3))
+        v = c + rng.normal(0, float(rng.choice([0.02, 0.3, 1.5])), (n, 3, 3))
+    elif kind == 1:    # lattice: exact ties everywhere (centroids, planes, edges, coplanar faces)
+        k = int(rng.integers(2, 7))
+        g = np.stack(np.meshgrid(np.arange(k), np.arange(k), np.arange(k), indexing="ij"), -1).reshape(-1, 1, 3).astype(np.float64)
+        offs = np.array([[[0, 0, 0], [1, 0, 0], [0, 1, 0]], [[0, 0, 0], [0, 1, 0], [0, 0, 1]], [[0, 0, 0], [0, 0, 1], [1, 0, 0]]], np.float64)
+        v = (g[:, None] + offs[None]).reshape(-1, 3, 3) - k / 2
+        v = v[rng.permutation(len(v))[: int(rng.integers(1, len(v) + 1))]]
+    elif kind == 2:    # duplicated and overlapping triangles (dist ties, COMBINE frames)
+        n = int(rng.integers(1, 60))
+        base = rng.uniform(-1.5, 1.5, (n, 3, 3))
+        v = np.concatenate([base] * int(rng.integers(2, 6)))
+        v = v[rng.permutation(len(v))]
+    elif kind == 3:    # closed room of big quads + clutter (rays never escape: deep paths)
+        r = 3.0
+        q = []
+        for ax in range(3):
+            for s in (-r, r):
+                a, b = [i for i in range(3) if i != ax]
+                p = np.zeros((4, 3)); p[:, ax] = s
+                p[:, a] = [-r, r, r, -r]; p[:, b] = [-r, -r, r, r]
+                q += [p[[0, 1, 2]], p[[0, 2, 3]]]
+        n = int(rng.integers(0, 400))
+        c = rng.uniform(-2, 2, (n, 1, 3))
+        v = np.concatenate([np.array(q), c + rng.normal(0, 0.25, (n, 3, 3))])
+    elif kind == 4:    # slivers and degenerate triangles (|a| near the 1e-4 cut-off, zero area)
+        n = int(rng.integers(20, 600))
+        a = rng.uniform(-2, 2, (n, 1, 3))
+        d = rng.normal(0, 1, (n, 1, 3))
+        t = rng.uniform(-1, 1, (n, 3, 1))
+        v = a + d * t + rng.normal(0, float(rng.choice([0, 1e-6, 1e-3])), (n, 3, 3))
+    else:              # axis-aligned thin plates through the origin (rays parallel to slab planes, zeros of both signs)
+        n = int(rng.integers(16, 300))
+        v = rng.uniform(-2, 2, (n, 3, 3))
+        ax = rng.integers(0, 3, n)
+        for i in range(n):
+            v[i, :, ax[i]] = float(rng.choice([0.0, -0.0, 1.0, -1.0]))
+    v = (v * scale).astype(np.float32)
+    nm = int(rng.integers(1, 6))
+    mats = np.zeros(nm, sqt._native.MAT_DTYPE)
+    mats["reflective"] = rng.choice([0.0, 0.0, 0.3, 1.0, 1.0], nm)
+    mats["surf"] = rng.uniform(0, 1, (nm, 3))
+    mats["emissive"] = rng.choice([0.0, 0.0, 1.0, 20.0], nm)
+    mats["emit"] = rng.uniform(0, 1, (nm, 3))
+    if rng.random() < 0.8:
+        mats["emissive"][nm - 1] = 15.0              # most scenes have a light
+    if rng.random() < 0.1:
+        mats["surf"][0, 0] = -0.5                    # negative component: the exact `== 0` shortcuts are off
+    if rng.random() < 0.05:
+        mats["emit"][0, 1] = np.inf                  # non-finite material: the emitter cull is off
+    mat = rng.integers(0, nm, len(v))
+    return v, mats, mat, scale
+
+
+def _fixed(x):
+    """Decimal text without exponent (the reference grammar has none), exact for the float32 it denotes."""
+    t = "%.40f" % float(np.float32(x))
+    return t.rstrip("0") + "0"
+
+
+def make_camera(rng, scale):
+    """A few candidate poses; the one whose central ray points best at the scene centre wins, so that most
+    cases see geometry (a quarter are left to chance: rays that miss everything are a case too)."""
+    mode = rng.integers(0, 4)
+    best = None
+    for _ in range(1 if rng.random() < 0.25 else 8):
+        if mode == 0:
+            pos = rng.uniform(-4, 4, 3) * scale
+            ang = rng.uniform(-3.2, 3.2, 3)
+        elif mode == 1:    # exact axis-aligned view from a lattice point
+            pos = rng.integers(-3, 4, 3).astype(np.float64) * scale
+            ang = rng.integers(-2, 3, 3) * (np.pi / 2)
+        elif mode == 2:    # from the origin / on box planes
+            pos = np.zeros(3)
+            ang = rng.uniform(-3.2, 3.2, 3)
+        else:
+            pos = rng.uniform(-0.5, 0.5, 3) * scale
+            ang = np.array([0.0, 0.0, 0.0]) if rng.random() < 0.3 else rng.uniform(-3.2, 3.2, 3)
+        text = (" ".join(_fixed(p) for p in pos) + "\n" + " ".join(_fixed(a) for a in ang) + "\n").encode()
+        cam = O.camera_from_text(text)
+        _, d = O.make_ray(8, 8, 4, 4, cam)
+        to_centre = -np.asarray(pos, np.float64)
+        score = float(np.dot(d, to_centre) / (np.linalg.norm(d) * (np.linalg.norm(to_centre) + 1e-30)))
+        if best is None or score > best[0]:
+            best = (score, text)
+    return best[1]
+
+
+def canon(a):
+    """uint32 view with every NaN mapped to one pattern (IEEE leaves NaN payloads to the implementation)."""
+    u = np.ascontiguousarray(a).view(np.uint32).copy()
+    u[np.isnan(a)] = 0x7FC00000
+    return u
+
+
+def run_case(seed):
+    rng = np.random.default_rng(seed)
+    v, mats, mat, scale = make_scene(rng)
+    camt = make_camera(rng, scale)
+    w, h = int(rng.integers(1, 49)), int(rng.integers(1, 49))
+    spp = int(rng.choice([1, 2, 3, 7, 16, 40]))
+    cast = bool(rng.random() < 0.15)
+    tris = np.zeros(len(v), sqt._native.TRI_DTYPE)
+    tris["v0"], tris["v1"], tris["v2"], tris["mat"] = v[:, 0], v[:, 1], v[:, 2], mat
+    mesh = sqt.Mesh.from_arrays(tris, mats)
+    on_device = bool(rng.random() < 0.5)
+    bih = sqt.BIH(mesh, device=0 if on_device else None)
+    ot = np.zeros(len(v), O.TRI_DTYPE)
+    ot["a"], ot["b"], ot["c"] = v[:, 0], v[:, 1], v[:, 2]
+    for f in ("reflective", "surf", "emissive", "emit"):
+        ot[f] = mats[f][mat]
+    ob = O.BIH(ot)
+    if (bih.height, bih.num_leaves, bih.longest_leaf) != (ob.height, ob.num_leaves, ob.longest_leaf):
+        return "tree shape differs (device build)" if on_device else "tree shape differs"
+    cam_p, cam_o = sqt.camera_from_text(camt), O.camera_from_text(camt)
+    o, o8, _ = ob.render(cam_o, spp, w, h, cast=cast, threads=THREADS)
+    ds = sqt.DeviceScene(bih, 0)
+    try:
+        for variant in (2, 1):
+            ds.set_option("variant", variant)
+            a, r = ds.render_rows(cam_p, spp, w, h, cast=cast)
+            torch.cuda.synchronize()
+            a, r = a.cpu().numpy(), r.cpu().numpy()
+            if not np.array_equal(canon(a), canon(o)):
+                bad = int((canon(a) != canon(o)).any(-1).sum())
+                return f"avg differs in {bad}/{w * h} pixels (variant {variant}, cast {cast}, tris {len(v)}, spp {spp}, {w}x{h})"
+            if not np.array_equal(r, o8):
+                return f"rgb8 differs (variant {variant})"
+    finally:
+        ds.close()
+    return None
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    t0 = time.time()
+    n = bad = 0
+    last = t0
+    while time.time() - t0 < budget:
+        msg = run_case(seed)
+        n += 1
+        if msg:
+            bad += 1
+            print(f"MISMATCH seed={seed}: {msg}", flush=True)
+        if time.time() - last > 30:
+            last = time.time()
+            print(f"... {n} cases, {bad} mismatches, next seed {seed + 1}", flush=True)
+        seed += 1
+    print(f"fuzz: {n} cases in {time.time() - t0:.0f} s, {bad} mismatches (seeds {seed - n}..{seed - 1})", flush=True)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
