@@ -2,7 +2,10 @@
 path against the CPU oracle, bit for bit (fp32 `avg` and RGB8).  Prints one line per mismatch with the seed
 that reproduces it, and a summary.  Checker use of the oracle only (like tests/).
 
-    python tools/gpu_fuzz.py [seconds=240] [first_seed=0]
+    python tools/gpu_fuzz.py [seconds=240] [first_seed=0] [big]
+
+`big`: frames up to 320 x 320 at up to 64 spp, scenes up to 20 000 triangles (the streaming kernel form), and a
+small sample-slot budget so that a frame takes several batches.
 """
 import importlib
 import os
@@ -22,13 +25,14 @@ sqt.lib()
 import torch  # noqa: E402
 
 THREADS = min(os.cpu_count() or 1, 16)
+BIG = "big" in sys.argv
 
 
 def make_scene(rng):
     kind = rng.integers(0, 6)
     scale = float(rng.choice([1e-3, 1.0, 1.0, 1.0, 50.0, 1e4]))
     if kind == 0:      # soup
-        n = int(rng.choice([1, 2, 14, 15, 16, 40, 200, 1000, 3000]))
+        n = int(rng.choice([3000, 8000, 20000] if BIG else [1, 2, 14, 15, 16, 40, 200, 1000, 3000]))
         c = rng.uniform(-2, 2, (n, 1, 3))
         v = c + rng.normal(0, float(rng.choice([0.02, 0.3, 1.5])), (n, 3, 3))
     elif kind == 1:    # lattice: exact ties everywhere (centroids, planes, edges, coplanar faces)
@@ -128,8 +132,8 @@ def run_case(seed):
     rng = np.random.default_rng(seed)
     v, mats, mat, scale = make_scene(rng)
     camt = make_camera(rng, scale)
-    w, h = int(rng.integers(1, 49)), int(rng.integers(1, 49))
-    spp = int(rng.choice([1, 2, 3, 7, 16, 40]))
+    w, h = (int(rng.integers(40, 321)), int(rng.integers(40, 321))) if BIG else (int(rng.integers(1, 49)), int(rng.integers(1, 49)))
+    spp = int(rng.choice([5, 16, 33, 64] if BIG else [1, 2, 3, 7, 16, 40]))
     cast = bool(rng.random() < 0.15)
     tris = np.zeros(len(v), sqt._native.TRI_DTYPE)
     tris["v0"], tris["v1"], tris["v2"], tris["mat"] = v[:, 0], v[:, 1], v[:, 2], mat
@@ -149,6 +153,8 @@ def run_case(seed):
     try:
         for variant in (2, 1):
             ds.set_option("variant", variant)
+            if BIG:
+                ds.set_option("slots", int(rng.choice([w * h, 3 * w * h + 17, 1 << 22])))
             a, r = ds.render_rows(cam_p, spp, w, h, cast=cast)
             torch.cuda.synchronize()
             a, r = a.cpu().numpy(), r.cpu().numpy()
