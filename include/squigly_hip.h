@@ -50,7 +50,12 @@ typedef struct {
 } sq_scene;
 
 /* ---- one-shot drop-in for src/Lib.hs:73-74 ---- */
-/* out: w*h*3 bytes, row-major, w ROWS x h COLUMNS (massiv `w :. h`, src/Lib.hs:70-71,80), RGB8 =
+/* The reference host is one process, so the one-shot calls put a node's GPUs to work themselves: rows are cut
+ * into interleaved blocks of 8 (the sq_shard scheme below), one host thread per device renders its shard, and
+ * the shards are de-interleaved into `out`; no exchange between devices is needed (a pixel depends only on
+ * x, y, samples, w).  Devices: all visible ones when the frame has >= 2^24 samples, else device 0; the
+ * environment variable SQ_DEVICES="0,1,3" names them explicitly (an index may repeat).
+ * out: w*h*3 bytes, row-major, w ROWS x h COLUMNS (massiv `w :. h`, src/Lib.hs:70-71,80), RGB8 =
  * rgbFloatToPixelRGB of each pixel (src/Lib.hs:93-104).  cast != 0 selects raycast (src/Lib.hs:141-151). */
 int sq_render_rgb8(const sq_scene* scene, const sq_camera* cam, int32_t samples, int32_t w, int32_t h,
                    int32_t cast, uint8_t* out);

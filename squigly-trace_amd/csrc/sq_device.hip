@@ -22,6 +22,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <type_traits>
 #include <unordered_map>
 #include <vector>
@@ -42,6 +43,7 @@ using namespace sqd;
 constexpr int kBlock = 256;        // per-pixel / per-sample kernels
 constexpr int kTraceBlock = 512;   // persistent trace kernel, streaming form: 8 waves share one LDS copy of the top of the tree
 constexpr int kResidentBlock = 1024; // persistent trace kernel, resident form: one workgroup per CU owns the whole scene in LDS
+constexpr int kOneshotRowBlock = 8; // rows per block when a one-shot call shards a frame over devices
 constexpr int kChunk = 128;        // rays a wave reserves from the queue per atomic (multiple of 64)
 
 // ----------------------------------------------------------------------------------------------
@@ -970,35 +972,104 @@ extern "C" int sq_set_option(sq_device_scene* s, const char* key, int64_t value)
 
 // ---- one-shot entry points (the drop-in for src/Lib.hs:73-74) ----
 namespace {
+// One shard of a one-shot call on one device: upload, render into a compact device buffer, copy back.
+struct OneshotPart {
+    int device = 0; sq_shard shard{ 1, 0, 1 };
+    std::vector<float> avg; std::vector<uint8_t> rgb;
+    int rc = 0; std::string error;
+};
+int oneshot_part(const sq_scene* scene, const sq_camera* cam, int32_t samples, int32_t w, int32_t h, int32_t cast,
+                 bool want_avg, bool want_rgb, OneshotPart& P) {
+    const int32_t rows = sq_shard_rows(w, P.shard);
+    if (rows <= 0) return 0;
+    sq_device_scene* s = nullptr;
+    if (sq_scene_upload(scene, P.device, &s)) return 1;
+    const size_t npx = (size_t)rows * (size_t)h * 3;
+    float* d_avg = nullptr; uint8_t* d_rgb = nullptr; hipStream_t stream = nullptr;
+    auto body = [&]() -> int {
+        SQ_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        if (want_avg) SQ_HIP(hipMalloc((void**)&d_avg, npx * sizeof(float)));
+        if (want_rgb) SQ_HIP(hipMalloc((void**)&d_rgb, npx));
+        if (sq_render_rows_device(s, cam, samples, w, h, cast, P.shard, d_avg, d_rgb, stream)) return 1;
+        SQ_HIP(hipStreamSynchronize(stream));
+        // staged through private buffers so nothing is written to the caller's memory on failure
+        if (want_avg) { P.avg.resize(npx); SQ_HIP(hipMemcpy(P.avg.data(), d_avg, npx * sizeof(float), hipMemcpyDeviceToHost)); }
+        if (want_rgb) { P.rgb.resize(npx); SQ_HIP(hipMemcpy(P.rgb.data(), d_rgb, npx, hipMemcpyDeviceToHost)); }
+        return 0;
+    };
+    const int rc = body();
+    (void)hipFree(d_avg); (void)hipFree(d_rgb);
+    if (stream) (void)hipStreamDestroy(stream);
+    sq_scene_free(s);
+    return rc;
+}
+
+// Devices a one-shot call spreads its rows over.  Default: every visible device when the frame is worth it
+// (>= 2^24 samples), else device 0.  SQ_DEVICES="0,1,3" names them explicitly; an index may repeat (several
+// shards on one device, which is how the threading is tested on a one-GPU box).
+int oneshot_devices(int64_t total_samples, int32_t w, std::vector<int>& out) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return sq_set_error("no HIP device available (this library has no CPU fallback)");
+    out.clear();
+    if (const char* env = std::getenv("SQ_DEVICES")) {
+        const char* p = env;
+        while (*p) {
+            char* end = nullptr;
+            const long v = std::strtol(p, &end, 10);
+            if (end == p || v < 0 || v >= ndev) return sq_set_error("SQ_DEVICES='%s': expected a comma-separated list of device indices in 0..%d", env, ndev - 1);
+            out.push_back((int)v);
+            p = end;
+            if (*p == ',') ++p;
+            else if (*p) return sq_set_error("SQ_DEVICES='%s': expected a comma-separated list of device indices in 0..%d", env, ndev - 1);
+        }
+        if (out.empty()) return sq_set_error("SQ_DEVICES is empty");
+        if (out.size() > 64) return sq_set_error("SQ_DEVICES names more than 64 shards");
+        return 0;
+    }
+    const int blocks = (w + kOneshotRowBlock - 1) / kOneshotRowBlock;
+    const int n = total_samples >= ((int64_t)1 << 24) ? std::min(ndev, std::max(blocks, 1)) : 1;
+    for (int d = 0; d < n; ++d) out.push_back(d);
+    return 0;
+}
+
+// The foreign call of src/Lib.hs:73-74.  The reference host is ONE process, so this is where a node's GPUs are
+// put to work for it: rows are cut into interleaved blocks of 8 (the sq_shard scheme), one host thread per
+// device renders its shard, and the shards are de-interleaved into the caller's image.  No exchange between
+// devices: a pixel depends only on (x, y, samples, w).
 int render_oneshot(const sq_scene* scene, const sq_camera* cam, int32_t samples, int32_t w, int32_t h, int32_t cast,
                    float* out_avg, uint8_t* out_rgb) {
     if (!scene || !cam || (!out_avg && !out_rgb)) return sq_set_error("null argument");
     if (samples < 1 || w < 1 || h < 1) return sq_set_error("samples, width and height must be positive (got %d, %d, %d)", samples, w, h);
-    sq_device_scene* s = nullptr;
-    if (sq_scene_upload(scene, 0, &s)) return 1;
-    const size_t npx = (size_t)w * (size_t)h * 3;
-    float* d_avg = nullptr; uint8_t* d_rgb = nullptr;
-    std::vector<float> h_avg; std::vector<uint8_t> h_rgb;
-    int rc = 0;
-    auto body = [&]() -> int {
-        if (out_avg) SQ_HIP(hipMalloc((void**)&d_avg, npx * sizeof(float)));
-        if (out_rgb) SQ_HIP(hipMalloc((void**)&d_rgb, npx));
-        sq_shard whole = { w, 0, 1 };
-        if (sq_render_rows_device(s, cam, samples, w, h, cast, whole, d_avg, d_rgb, nullptr)) return 1;
-        SQ_HIP(hipDeviceSynchronize());
-        // stage through private buffers so nothing is written to the caller's memory on failure
-        if (out_avg) { h_avg.resize(npx); SQ_HIP(hipMemcpy(h_avg.data(), d_avg, npx * sizeof(float), hipMemcpyDeviceToHost)); }
-        if (out_rgb) { h_rgb.resize(npx); SQ_HIP(hipMemcpy(h_rgb.data(), d_rgb, npx, hipMemcpyDeviceToHost)); }
-        return 0;
+    std::vector<int> devices;
+    if (oneshot_devices((int64_t)w * h * samples, w, devices)) return 1;
+    const int G = (int)devices.size();
+    std::vector<OneshotPart> parts((size_t)G);
+    for (int g = 0; g < G; ++g) { parts[(size_t)g].device = devices[(size_t)g]; parts[(size_t)g].shard = sq_shard{ G == 1 ? w : kOneshotRowBlock, g, G }; }
+    auto run = [&](OneshotPart& P) {
+        P.rc = oneshot_part(scene, cam, samples, w, h, cast, out_avg != nullptr, out_rgb != nullptr, P);
+        if (P.rc) P.error = sq_last_error();                      // the message is thread-local: carry it out
     };
-    rc = body();
-    (void)hipFree(d_avg); (void)hipFree(d_rgb);
-    sq_scene_free(s);
-    if (rc) return rc;
-    if (out_avg) std::memcpy(out_avg, h_avg.data(), npx * sizeof(float));
-    if (out_rgb) std::memcpy(out_rgb, h_rgb.data(), npx);
+    if (G == 1) run(parts[0]);
+    else {
+        std::vector<std::thread> threads;
+        for (int g = 1; g < G; ++g) threads.emplace_back(run, std::ref(parts[(size_t)g]));
+        run(parts[0]);
+        for (auto& t : threads) t.join();
+    }
+    for (const OneshotPart& P : parts)
+        if (P.rc) return sq_set_error("device %d (shard %d of %d): %s", P.device, P.shard.shard, G, P.error.c_str());
+    const size_t row_px = (size_t)h * 3;
+    for (const OneshotPart& P : parts) {
+        const int32_t rows = sq_shard_rows(w, P.shard);
+        for (int32_t j = 0; j < rows; ++j) {
+            const size_t dst = (size_t)sq_shard_global_row(j, P.shard) * row_px, src = (size_t)j * row_px;
+            if (out_avg) std::memcpy(out_avg + dst, P.avg.data() + src, row_px * sizeof(float));
+            if (out_rgb) std::memcpy(out_rgb + dst, P.rgb.data() + src, row_px);
+        }
+    }
     return 0;
 }
+
 }  // namespace
 
 extern "C" int sq_render_rgb8(const sq_scene* scene, const sq_camera* cam, int32_t samples, int32_t w, int32_t h, int32_t cast, uint8_t* out) {

@@ -401,3 +401,29 @@ def test_randomised_campaign(sqt, O):
     import gpu_fuzz
     failures = [(seed, msg) for seed in range(1000, 1400) if (msg := gpu_fuzz.run_case(seed))]
     assert not failures, failures[:5]
+
+
+def test_one_shot_call_spreads_over_devices(sqt, product_scene, oracle_scene, monkeypatch):
+    """sq_render_rgb8 / sq_render_f32 shard the rows over SQ_DEVICES (default: every visible GPU for large frames),
+    one host thread per device, and de-interleave the result.  On a one-GPU box the same device is named several
+    times: the threading, the 8-row interleave and the ragged last block are what is under test."""
+    bih, cam, _ = product_scene
+    ob, ocam, _ = oracle_scene
+    want = np.load(os.path.join(GOLDEN, "scene_64x64_4spp_avg.npy"))
+    for devs in ("0", "0,0", "0,0,0", "0,0,0,0,0,0,0,0,0,0,0"):          # 11 shards of a 64-row frame: three get no rows
+        monkeypatch.setenv("SQ_DEVICES", devs)
+        assert np.array_equal(bits(sqt.render_f32(bih, cam, 4, (64, 64))), bits(want)), devs
+        assert np.array_equal(sqt.render_rgb8(bih, cam, 4, (64, 64)), np.load(os.path.join(GOLDEN, "scene_64x64_4spp_rgb8.npy"))), devs
+    monkeypatch.setenv("SQ_DEVICES", "0,0,0")
+    o, o8, _ = ob.render(ocam, 5, 37, 29, threads=THREADS)                # 37 rows: blocks of 8,8,8,8,5
+    assert np.array_equal(bits(sqt.render_f32(bih, cam, 5, (37, 29))), bits(o))
+    assert np.array_equal(sqt.render_rgb8(bih, cam, 5, (37, 29)), o8)
+    oc, _, _ = ob.render(ocam, 1, 37, 29, cast=True, threads=THREADS)
+    assert np.array_equal(bits(sqt.render_f32(bih, cam, 1, (37, 29), cast=True)), bits(oc))
+    for bad in ("0,x", "99", "", "0,,1", "-1"):
+        monkeypatch.setenv("SQ_DEVICES", bad)
+        out = np.full((8, 8, 3), 7, np.uint8)
+        with pytest.raises(sqt.SquiglyError, match="SQ_DEVICES"):
+            sqt.render_rgb8(bih, cam, 1, (8, 8))
+    monkeypatch.delenv("SQ_DEVICES")
+    assert np.array_equal(bits(sqt.render_f32(bih, cam, 4, (64, 64))), bits(want))
