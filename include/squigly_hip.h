@@ -97,7 +97,10 @@ int  sq_get_stats(sq_device_scene* s, uint64_t* out, int32_t n, int32_t reset);
  *   "straggler_lanes"    lanes still traversing when a wave turns to its leaves (default 6)
  *   "trace_blocks_per_cu" streaming form: workgroups per CU (0 = as many as LDS allows, up to 4)
  *   "timing"             1 = bracket the dominant kernel with hipEvents for sq_kernel_timing (default 0)
- *   "profile"            1 = lane-occupancy counters in sq_get_stats (slower) */
+ *   "profile"            1 = lane-occupancy counters in sq_get_stats (slower)
+ *   "overlap"            1 = two sample batches in flight: trace launches on the caller's stream, the per-sample
+ *                        kernels beside them on an internal stream (+3 % measured; default 0)
+ *   "aux_blocks_per_cu"  workgroups per CU of the per-sample kernels (0 = default 8) */
 int  sq_set_option(sq_device_scene* s, const char* key, int64_t value);
 
 /* Diagnostics for the numeric spec (tests only): evaluate one primitive on the device for n inputs.
