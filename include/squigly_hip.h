@@ -63,6 +63,11 @@ int sq_render_rgb8(const sq_scene* scene, const sq_camera* cam, int32_t samples,
 int sq_render_f32(const sq_scene* scene, const sq_camera* cam, int32_t samples, int32_t w, int32_t h,
                   int32_t cast, float* out_avg);
 
+/* Frame workspaces (up to 32 GB for a 1080p frame at 256 spp) are kept, one block per device, when a scene is
+ * freed, so that repeated one-shot calls do not re-allocate them (a hipMalloc right after the hipFree of a block
+ * that large can wait seconds for the driver to scrub it).  This hands them back to the driver. */
+void sq_release_cached_memory(void);
+
 /* ---- resident API: scene stays in HBM, output stays on the device (bench, multi-GPU) ---- */
 typedef struct sq_device_scene sq_device_scene;
 int  sq_scene_upload(const sq_scene* scene, int32_t device, sq_device_scene** out);

@@ -21,6 +21,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <type_traits>
@@ -745,12 +746,44 @@ extern "C" int sq_scene_upload(const sq_scene* sc, int32_t device, sq_device_sce
     return 0;
 }
 
+// Frame workspaces outlive the scene that allocated them: one block per device is kept for the next scene
+// (sq_release_cached_memory() returns it).  The one-shot calls create and free a scene per frame, and a
+// hipMalloc that follows the hipFree of a 32 GB block can wait seconds for the driver to scrub it.
+namespace {
+struct CachedBlock { void* ptr = nullptr; size_t bytes = 0; };
+std::mutex g_cache_mutex;
+CachedBlock g_cache[64];
+void* cache_take(int device, size_t bytes, size_t* got) {   // a block of at least `bytes` (its size in *got), or nullptr
+    std::lock_guard<std::mutex> lock(g_cache_mutex);
+    CachedBlock& c = g_cache[device & 63];
+    if (!c.ptr || c.bytes < bytes) return nullptr;
+    void* p = c.ptr; *got = c.bytes; c = CachedBlock{};
+    return p;
+}
+void cache_give(int device, void* ptr, size_t bytes) { // keeps the larger block, frees the other
+    void* drop = ptr;
+    {
+        std::lock_guard<std::mutex> lock(g_cache_mutex);
+        CachedBlock& c = g_cache[device & 63];
+        if (bytes > c.bytes) { drop = c.ptr; c.ptr = ptr; c.bytes = bytes; }
+    }
+    if (drop) (void)hipFree(drop);
+}
+}  // namespace
+extern "C" void sq_release_cached_memory(void) {
+    for (int d = 0; d < 64; ++d) {
+        size_t got = 0;
+        void* p = cache_take(d, 0, &got);
+        if (p && hipSetDevice(d) == hipSuccess) (void)hipFree(p);
+    }
+}
+
 extern "C" void sq_scene_free(sq_device_scene* s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
     for (auto& p : s->pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     (void)hipFree(s->d_branches); (void)hipFree(s->d_leaves); (void)hipFree(s->d_tris); (void)hipFree(s->d_mats); (void)hipFree(s->d_verts); (void)hipFree(s->d_trix); (void)hipFree(s->d_rbranch); (void)hipFree(s->d_emitters); (void)hipFree(s->d_tri_mat);
-    (void)hipFree(s->d_work);
+    if (s->d_work) cache_give(s->device, s->d_work, s->work_bytes);
     for (hipEvent_t e : s->events) (void)hipEventDestroy(e);
     if (s->aux) (void)hipStreamDestroy(s->aux);
     delete s;
@@ -780,7 +813,8 @@ int ensure_workspace(sq_device_scene* s, int64_t pixels, int64_t slots) {
     if (pixels <= s->work_pixels && slots <= s->work_slots && s->d_work) return 0;
     pixels = std::max(pixels, s->work_pixels); slots = std::max(slots, s->work_slots);
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    if (s->d_work) { (void)hipFree(s->d_work); s->d_work = nullptr; s->work_pixels = s->work_slots = 0; }
+    if (s->d_work) { cache_give(s->device, s->d_work, s->work_bytes); s->d_work = nullptr; s->work_pixels = s->work_slots = 0; }
+    size_t block_bytes = 0;
     size_t off = 0, o_cnt = 0, o_stats = 0, o_pix = 0, o_t0 = 0, o_tri0 = 0, o_sum = 0, o_mt = 0, o_mtri = 0, o_org = 0, o_dir = 0, o_hit = 0, o_rng = 0, o_rad = 0;
     for (;;) {
         off = 0;
@@ -789,6 +823,8 @@ int ensure_workspace(sq_device_scene* s, int64_t pixels, int64_t slots) {
         o_pix = take(pixels * 4); o_t0 = take(pixels * 4); o_tri0 = take(pixels * 4); o_sum = take(pixels * 12);
         o_mt = take(pixels * 4); o_mtri = take(pixels * 4);
         o_org = take(slots * 16); o_dir = take(slots * 16); o_hit = take(slots * 8); o_rng = take(slots * 8); o_rad = take(slots * 12);
+        block_bytes = off;
+        if ((s->d_work = cache_take(s->device, off, &block_bytes)) != nullptr) break;
         if (hipMalloc(&s->d_work, off) == hipSuccess) break;
         (void)hipGetLastError();
         s->d_work = nullptr;
@@ -806,7 +842,7 @@ int ensure_workspace(sq_device_scene* s, int64_t pixels, int64_t slots) {
     W.org = (float4*)(base + o_org); W.dir = (float4*)(base + o_dir); W.hit = (int2*)(base + o_hit);
     W.rng12 = (uint2*)(base + o_rng); W.rad = (float*)(base + o_rad);
     W.slot_capacity = slots;
-    s->work_bytes = off; s->work_pixels = pixels; s->work_slots = slots;
+    s->work_bytes = block_bytes; s->work_pixels = pixels; s->work_slots = slots;
     return 0;
 }
 

@@ -430,3 +430,6 @@ def test_one_shot_call_spreads_over_devices(sqt, product_scene, oracle_scene, mo
             sqt.render_rgb8(bih, cam, 1, (8, 8))
     monkeypatch.delenv("SQ_DEVICES")
     assert np.array_equal(bits(sqt.render_f32(bih, cam, 4, (64, 64))), bits(want))
+    # the frame workspace a freed scene leaves behind for the next one-shot call can be handed back, and comes back
+    sqt.lib().sq_release_cached_memory()
+    assert np.array_equal(bits(sqt.render_f32(bih, cam, 4, (64, 64))), bits(want))
