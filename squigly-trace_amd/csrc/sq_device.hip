@@ -604,6 +604,7 @@ extern "C" int sq_scene_upload(const sq_scene* sc, int32_t device, sq_device_sce
         for (auto& level : by_depth) for (int32_t i : level) ref[(size_t)i] = (uint32_t)nb++;
     }
     std::vector<DevBranch> br((size_t)nb);
+    std::vector<int> br_axis((size_t)nb);
     std::vector<DevLeaf> lf((size_t)nl);
     std::vector<sq_bounds> box((size_t)n);
     box[0] = sc->root;
@@ -614,7 +615,7 @@ extern "C" int sq_scene_upload(const sq_scene* sc, int32_t device, sq_device_sce
         const sq_bounds& b = box[(size_t)i];
         DevBranch& d = br[ref[(size_t)i]];
         for (int c = 0; c < 3; ++c) { d.lo[c] = b.lo[c]; d.hi[c] = b.hi[c]; }
-        d.lmax = nd.lmax; d.rmin = nd.rmin; d.axis = kind; d.pad = 0;
+        d.lmax = d.lmax2 = nd.lmax; d.rmin = d.rmin2 = nd.rmin; br_axis[ref[(size_t)i]] = kind;
         d.left = ref[(size_t)i + 1]; d.right = ref[(size_t)nd.link];
         sq_bounds l = b, r = b;                          // src/BIH.hs:130-141
         l.hi[kind] = nd.lmax; r.lo[kind] = nd.rmin;
@@ -679,7 +680,7 @@ extern "C" int sq_scene_upload(const sq_scene* sc, int32_t device, sq_device_sce
                 const DevBranch& d = br[(size_t)i];
                 uint32_t* r = &rbranch[(size_t)i * 10];
                 std::memcpy(r, d.lo, 12); std::memcpy(r + 3, &d.lmax, 4); std::memcpy(r + 4, d.hi, 12); std::memcpy(r + 7, &d.rmin, 4);
-                r[8] = enc(d.left) | ((uint32_t)d.axis << 29); r[9] = enc(d.right);
+                r[8] = enc(d.left) | ((uint32_t)br_axis[(size_t)i] << 29); r[9] = enc(d.right);
             }
             rroot = enc(ref[0]);
         } else { trix.clear(); }
@@ -687,15 +688,20 @@ extern "C" int sq_scene_upload(const sq_scene* sc, int32_t device, sq_device_sce
     // Streaming form: leaf references carry (first, count) themselves when they fit, which saves the dependent
     // leaf-table load of every leaf visit.
     bool packed_leaves = sc->n_tris < (1 << 24);
-    for (int32_t i = 0; i < nl && packed_leaves; ++i) packed_leaves = lf[(size_t)i].count <= 127;
+    for (int32_t i = 0; i < nl && packed_leaves; ++i) packed_leaves = lf[(size_t)i].count <= 31;
+    if (nb >= (1 << 29) || nl >= (1 << 29)) { sq_set_error("scene has %d branches and %d leaves; the device layout holds 2^29 of each", nb, nl); return 1; }
     uint32_t root_ref = ref[0];
-    if (packed_leaves) {
+    {
         auto enc = [&](uint32_t r) -> uint32_t {
-            if (!(r & kLeafBit)) return r;
+            if (!packed_leaves || !(r & kLeafBit)) return r;
             const DevLeaf& L = lf[r & ~kLeafBit];
             return kLeafBit | ((uint32_t)L.count << 24) | (uint32_t)L.first;
         };
-        for (DevBranch& d : br) { d.left = enc(d.left); d.right = enc(d.right); }
+        for (int32_t i = 0; i < nb; ++i) {
+            DevBranch& d = br[(size_t)i];
+            d.left = enc(d.left) | ((uint32_t)br_axis[(size_t)i] << 29);   // kAxisMask bits
+            d.right = enc(d.right);
+        }
         root_ref = enc(root_ref);
     }
     // Emissive triangles (for the last-bounce shortcut of sq_shade1).  Disabled (-1) when a material value is not

@@ -24,7 +24,8 @@ template <typename T> __device__ __forceinline__ SQ_LDS T* to_lds(void* generic)
 struct DevBranch {          // 48 B, three 16-byte quads
     float lo[3]; float lmax;    // traversal box of THIS branch: root bounds clipped along the path (src/BIH.hs:130-141)
     float hi[3]; float rmin;
-    int32_t axis; uint32_t left, right; int32_t pad;
+    float lmax2, rmin2;         // the third quad alone serves a return into this branch (planes, axis, children):
+    uint32_t left, right;       //   one 16-byte load instead of three.  Bits 30..29 of `left` hold the split axis.
 };
 struct DevLeaf { int32_t first, count; };
 struct DevTri {             // 36 B: v0 | e1 = v1 - v0 | e2 = v2 - v0 (same rounding as src/Geometry.hs:130-131).
@@ -42,7 +43,7 @@ struct SceneView {
     const float4* mats;       // 2 quads per material
     float root_lo[3], root_hi[3];
     uint32_t root_ref;
-    int32_t packed_leaves;    // 1: a leaf reference is kLeafBit | count << 24 | first (count <= 127, < 2^24 triangles), no table lookup
+    int32_t packed_leaves;    // 1: a leaf reference is kLeafBit | count << 24 | first (count <= 31, < 2^24 triangles), no table lookup
     int32_t n_branches, n_leaves, n_tris, n_mats;
     // Resident (LDS) form of the same scene, present when it can be encoded (16-bit vertex indices, leaves
     // of at most 31 triangles, < 2^24 triangles/branches): see "resident encoding" below.
@@ -202,14 +203,26 @@ template <> struct StackTraits<uint32_t> { static constexpr uint32_t flag = 0x80
 // kLeafBit; the triangle source of the same kernel knows how to turn a leaf reference into a range.
 struct BranchData { v4f q0, q1; int axis; uint32_t left, right; };   // q0 = lo.xyz,lmax ; q1 = hi.xyz,rmin
 
+struct BranchTail { float lmax, rmin; int axis; uint32_t left, right; };   // what a return into a branch needs
+constexpr uint32_t kAxisMask = 0x60000000u;     // bits 30..29 of a branch's LEFT reference word: the split axis
+
+__device__ __forceinline__ BranchTail unpack_tail(v4f q2) {
+    const uint32_t l = __float_as_uint(q2.z);
+    return BranchTail{ q2.x, q2.y, (int)((l >> 29) & 3u), l & ~kAxisMask, __float_as_uint(q2.w) };
+}
 __device__ __forceinline__ BranchData unpack_branch(v4f q0, v4f q1, v4f q2) {
-    return BranchData{ q0, q1, __float_as_int(q2.x), __float_as_uint(q2.y), __float_as_uint(q2.z) };
+    const BranchTail t = unpack_tail(q2);
+    return BranchData{ q0, q1, t.axis, t.left, t.right };
 }
 struct GlobalNodes {            // every branch read from HBM/L2
     const float4* g;
     __device__ __forceinline__ BranchData load(uint32_t b) const {
         const float4 a = g[3 * b], c = g[3 * b + 1], d = g[3 * b + 2];
         return unpack_branch(v4f{ a.x, a.y, a.z, a.w }, v4f{ c.x, c.y, c.z, c.w }, v4f{ d.x, d.y, d.z, d.w });
+    }
+    __device__ __forceinline__ BranchTail tail(uint32_t b) const {
+        const float4 d = g[3 * b + 2];
+        return unpack_tail(v4f{ d.x, d.y, d.z, d.w });
     }
 };
 struct HybridNodes {            // first n_lds branches (top of the tree) in LDS, the rest from HBM/L2
@@ -219,17 +232,26 @@ struct HybridNodes {            // first n_lds branches (top of the tree) in LDS
         const float4 a = g[3 * b], c = g[3 * b + 1], d = g[3 * b + 2];
         return unpack_branch(v4f{ a.x, a.y, a.z, a.w }, v4f{ c.x, c.y, c.z, c.w }, v4f{ d.x, d.y, d.z, d.w });
     }
+    __device__ __forceinline__ BranchTail tail(uint32_t b) const {
+        if (b < n_lds) return unpack_tail(l[3 * b + 2]);
+        const float4 d = g[3 * b + 2];
+        return unpack_tail(v4f{ d.x, d.y, d.z, d.w });
+    }
 };
 // Resident encoding (whole scene in LDS).  A branch is 40 B: two 16-B quads and two reference words.
 //   reference word: bit 31 = leaf; leaf: bits 28..24 = triangle count (<= 31), bits 23..0 = first triangle;
 //                   branch: bits 23..0 = branch index.  Bits 30..29 of the LEFT word hold the split axis.
-constexpr uint32_t kResAxisMask = 0x60000000u;
+constexpr uint32_t kResAxisMask = kAxisMask;
 struct ResidentNodes {
     const SQ_LDS v4f* quads;      // 2 per branch
     const SQ_LDS v2i* refs;       // 1 per branch
     __device__ __forceinline__ BranchData load(uint32_t b) const {
         const v2i r = refs[b];
         return BranchData{ quads[2 * b], quads[2 * b + 1], (int)(((uint32_t)r.x >> 29) & 3u), (uint32_t)r.x & ~kResAxisMask, (uint32_t)r.y };
+    }
+    __device__ __forceinline__ BranchTail tail(uint32_t b) const {
+        const v2i r = refs[b];
+        return BranchTail{ quads[2 * b].w, quads[2 * b + 1].w, (int)(((uint32_t)r.x >> 29) & 3u), (uint32_t)r.x & ~kResAxisMask, (uint32_t)r.y };
     }
 };
 
@@ -266,7 +288,7 @@ struct GlobalTris {
         }
     }
     __device__ __forceinline__ int2 leaf(uint32_t ref) const {
-        if (packed) return make_int2((int)(ref & 0xFFFFFFu), (int)((ref >> 24) & 127u));   // saves a dependent load per leaf visit
+        if (packed) return make_int2((int)(ref & 0xFFFFFFu), (int)((ref >> 24) & 31u));   // saves a dependent load per leaf visit
         return leaves[ref & ~kLeafBit];
     }
 };
@@ -396,13 +418,12 @@ __device__ __forceinline__ void trav_unwind(Trav& T, const NodeSrc& N, const Tri
         if (T.R.tri < 0 || !dist_gt(T.o, T.d, nt, T.R.t)) { T.R.t = nt; T.R.tri = ntri; }   // ties keep near
         return;
     }
-    const BranchData B = N.load(e);                                     // back in branch e: its near child returned R
-    const v4f q0 = B.q0, q1 = B.q1;
+    const BranchTail B = N.tail(e);                                     // back in branch e: its near child returned R
     const int ax = B.axis;
     const bool l2r = sq::axis_of(T.d, ax) > 0;
     if (T.R.tri >= 0) {
         const float p = sq::axis_of(T.o, ax) + T.R.t * sq::axis_of(T.d, ax);   // projectToAxis ax (intersectPoint near)
-        const bool close = l2r ? (p < q1.w) : (p > q0.w);               // isClose, src/BIH.hs:121-123
+        const bool close = l2r ? (p < B.rmin) : (p > B.lmax);           // isClose, src/BIH.hs:121-123
         if (close) return;                                              // src/BIH.hs:114: the branch returns near
         stk[T.sp * stride] = (StackT)((uint32_t)T.R.tri | flag);        // COMBINE(R)
         T.csp = T.sp; T.ct = T.R.t; ++T.sp;
