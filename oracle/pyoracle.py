@@ -1,7 +1,7 @@
 """ctypes binding of oracle/libsq_oracle.so — TEST INFRASTRUCTURE ONLY.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
-Nothing under squigly-trace_amd/ imports it (tests/test_no_oracle_in_product.py enforces that).
+Nothing under squigly-trace_amd/ imports it (tests/test_host.py::test_product_does_not_touch_the_oracle enforces that).
 """
 import ctypes as C
 import os

@@ -123,9 +123,11 @@ def test_render_without_gpu_fails_loudly_not_silently(sqt, product_scene):
     """No CPU fallback: without a HIP device the render entry point returns an error."""
     if sqt.device_count() > 0:
         pytest.skip("a GPU is present")
-    bih, cam, _ = product_scene
+    bih, cam, mesh = product_scene
     with pytest.raises(sqt.SquiglyError, match="no HIP device|no CPU fallback"):
         sqt.render_rgb8(bih, cam, 1, (4, 4))
+    with pytest.raises(sqt.SquiglyError, match="no HIP device"):
+        sqt.BIH(mesh, device=0)                      # the GPU build does not quietly become the host build
 
 
 def test_shard_helpers(sqt):
