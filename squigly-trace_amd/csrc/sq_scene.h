@@ -302,6 +302,13 @@ struct ResidentTris {           // whole scene resident in LDS: 16-bit indexed t
         e1 = sq::mk(b.x, b.y, b.z) - v0;
         e2 = sq::mk(c.x, c.y, c.z) - v0;
     }
+    __device__ __forceinline__ v4us index(int i) const { return trix[i]; }
+    __device__ __forceinline__ void get_indexed(v4us r, f3& v0, f3& e1, f3& e2) const {
+        const v4f a = verts[r.x], b = verts[r.y], c = verts[r.z];
+        v0 = sq::mk(a.x, a.y, a.z);
+        e1 = sq::mk(b.x, b.y, b.z) - v0;
+        e2 = sq::mk(c.x, c.y, c.z) - v0;
+    }
     __device__ __forceinline__ int2 leaf(uint32_t ref) const { return make_int2((int)(ref & 0xFFFFFFu), (int)((ref >> 24) & 31u)); }
 };
 
@@ -391,6 +398,21 @@ __device__ __forceinline__ void trav_leaf(Trav& T, const TriSrc& G) {
             leaf_fold(T, v0[1], e1[1], e2[1], i + 1);
         }
     }
+    if constexpr (!TriSrc::kPairLoads) {
+        // LDS-resident: a triangle costs two dependent LDS round trips (index record, then vertices); the next
+        // triangle's index record is read one iteration ahead (8 bytes; the read past the last record stays in LDS).
+        if (i < end) {
+            auto r = G.index(i);
+            for (; i < end; ++i) {
+                const auto cur = r;
+                r = G.index(i + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                f3 v0, e1, e2;
+                G.get_indexed(cur, v0, e1, e2);
+                leaf_fold(T, v0, e1, e2, i);
+            }
+        }
+    } else
     for (; i < end; ++i) {
         f3 v0, e1, e2;
         G.get(i, v0, e1, e2);
