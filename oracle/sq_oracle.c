@@ -139,7 +139,8 @@ double sqo_atan_d(double x) {
     p = p * z + -0x1.2492492492492p-3;        /* -1/7  */
     p = p * z + 0x1.999999999999ap-3;         /* +1/5  */
     p = p * z + -0x1.5555555555555p-2;        /* -1/3  */
-    double r = TAB[(int)kf] + (t + (t * z) * p);
+    int k = (kf >= 0.0 && kf <= 8.0) ? (int)kf : 0;   /* NaN input: any entry, the sum is NaN anyway */
+    double r = TAB[k] + (t + (t * z) * p);
     if (inv) r = PIO2 - r;
     return (x < 0) ? -r : r;
 }

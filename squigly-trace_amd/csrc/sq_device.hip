@@ -745,6 +745,15 @@ extern "C" int sq_scene_upload(const sq_scene* sc, int32_t device, sq_device_sce
     v.root_ref = root_ref; v.packed_leaves = packed_leaves ? 1 : 0;
     v.n_branches = nb; v.n_leaves = nl; v.n_tris = sc->n_tris; v.n_mats = sc->n_mats;
     v.height = height; v.nonneg_materials = nonneg ? 1 : 0;
+    {
+        bool fin = true;
+        auto ok = [](float c) { return c - c == 0.0f; };
+        for (const DevBranch& d : br) for (int c = 0; c < 3; ++c) fin = fin && ok(d.lo[c]) && ok(d.hi[c]);
+        for (const DevBranch& d : br) fin = fin && ok(d.lmax) && ok(d.rmin);
+        for (int c = 0; c < 3; ++c) fin = fin && ok(sc->root.lo[c]) && ok(sc->root.hi[c]);
+        for (int32_t i = 0; i < sc->n_tris && fin; ++i) for (int c = 0; c < 3; ++c) fin = fin && ok(sc->tris[i].v0[c]) && ok(sc->tris[i].v1[c]) && ok(sc->tris[i].v2[c]);
+        v.finite_geometry = fin ? 1 : 0;
+    }
     v.verts4 = (const float4*)s->d_verts; v.trix = trix.empty() ? nullptr : (const ushort4*)s->d_trix; v.n_verts = (int32_t)(uverts.size() / 4);
     v.rbranch = (const uint32_t*)s->d_rbranch; v.rroot = rroot;
     v.emitters = (const int32_t*)s->d_emitters; v.n_emitters = n_emitters;

@@ -54,6 +54,7 @@ struct SceneView {
     int32_t n_verts;
     int32_t height;           // BIH.height; a traversal never holds more than height-1 frames
     int32_t nonneg_materials; // 1 if every material component is >= +0 (enables the exact s == 0 shortcuts)
+    int32_t finite_geometry;  // 1 if every vertex and box coordinate is finite (v_min/v_max slabs need NaN-free planes)
     const int32_t* emitters;  // triangles whose emission `emissive *^ emitColor` is not exactly (+0,+0,+0)
     int32_t n_emitters;       // their number, or -1 when the last-bounce shortcut is disabled (see sq_shade1)
 };
@@ -109,13 +110,18 @@ __device__ __forceinline__ float hit_dist(f3 o, f3 d, float t) {
     const f3 p = o + sq::scale(t, d);
     return sq::norm(p - o);
 }
-// `compare (dist a) (dist b) == GT` for two hits of the SAME ray, given their t.
+// `compare (dist a) (dist b) == GT` for two hits of the SAME ray, given their t.  Haskell's `compare` on Floats
+// answers GT whenever neither `<` nor `==` holds, so a NaN distance compares GT both ways (sq::cmp_gt).
 // hit_dist is monotone non-decreasing in t: t*d_k, o_k + (.), (.) - o_k, squaring of a value whose sign is
-// fixed by d_k, the two additions and the square root are each monotone under round-to-nearest.  So
+// fixed by d_k, the two additions and the square root are each monotone under round-to-nearest.  So for a ray
+// with finite origin and direction and two finite t (then no distance is NaN: overflow only makes +inf),
 // ta <= tb implies dist(a) <= dist(b), i.e. not GT, and the distances are only evaluated when ta > tb
 // (where equal rounded distances still give "not GT", exactly as the reference's tie rule needs).
-__device__ __forceinline__ bool dist_gt(f3 o, f3 d, float ta, float tb) {
-    if (!(ta > tb)) return false;
+// A hit can carry t = +inf (f * dot overflows and still passes `t > eps`); its point has a NaN wherever the
+// direction has a zero, its distance is NaN, and the shortcut must not be taken.
+__device__ __forceinline__ bool dist_gt(f3 o, f3 d, float ta, float tb, bool finite_ray) {
+    const float inf = __builtin_inff();
+    if (finite_ray && ta < inf && tb < inf && !(ta > tb)) return false;
     return sq::cmp_gt(hit_dist(o, d, ta), hit_dist(o, d, tb));
 }
 
@@ -317,7 +323,7 @@ struct Trav {
     uint32_t cur;
     int sp, mode;
     Hit R;
-    bool safe;          // o, d, 1/d all finite: slab_fast is exact for this ray
+    bool safe;          // o, d, 1/d and every box coordinate finite: slab_fast and the dist_gt shortcut are exact for this ray
     int csp;            // stack index of the COMBINE frame whose t is cached below, or -1
     float ct;
 };
@@ -325,7 +331,7 @@ struct Trav {
 __device__ __forceinline__ void trav_begin(Trav& T, const SceneView& S, uint32_t root_ref, f3 o, f3 d) {
     T.o = o; T.d = d; T.df = sq::mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     T.cur = root_ref; T.sp = 0; T.R.t = 0; T.R.tri = -1;
-    T.safe = finite3(o) && finite3(d) && finite3(T.df);
+    T.safe = S.finite_geometry && finite3(o) && finite3(d) && finite3(T.df);
     T.csp = -1; T.ct = 0;
     T.mode = (T.cur & kLeafBit) ? M_LEAF : M_DESCEND;
     if (T.mode == M_DESCEND &&
@@ -366,7 +372,7 @@ __device__ __forceinline__ void trav_descend(Trav& T, const NodeSrc& N, SQ_LDS S
 __device__ __forceinline__ void leaf_fold(Trav& T, f3 v0, f3 e1, f3 e2, int i) {
     float t;
     if (moller_trumbore(T.o, T.d, v0, e1, e2, t)) {
-        if (T.R.tri < 0 || dist_gt(T.o, T.d, T.R.t, t)) { T.R.t = t; T.R.tri = i; }   // replace only on GT
+        if (T.R.tri < 0 || dist_gt(T.o, T.d, T.R.t, t, T.safe)) { T.R.t = t; T.R.tri = i; }   // replace only on GT
     }
 }
 // The whole Leaf equation, triangles in leaf order.  Pre: mode == M_LEAF.
@@ -437,7 +443,7 @@ __device__ __forceinline__ void trav_unwind(Trav& T, const NodeSrc& N, const Tri
             (void)moller_trumbore(T.o, T.d, v0, e1, e2, nt);
         }
         T.csp = -1;
-        if (T.R.tri < 0 || !dist_gt(T.o, T.d, nt, T.R.t)) { T.R.t = nt; T.R.tri = ntri; }   // ties keep near
+        if (T.R.tri < 0 || !dist_gt(T.o, T.d, nt, T.R.t, T.safe)) { T.R.t = nt; T.R.tri = ntri; }   // ties keep near
         return;
     }
     const BranchTail B = N.tail(e);                                     // back in branch e: its near child returned R

@@ -404,6 +404,10 @@ def test_randomised_campaign(sqt, O):
     import gpu_fuzz
     failures = [(seed, msg) for seed in range(1000, 1400) if (msg := gpu_fuzz.run_case(seed))]
     assert not failures, failures[:5]
+    # Found by the campaign: coordinates around 1e19 make `f * dot e2 q` overflow, the hit has t = +inf, its point
+    # has a NaN where the direction has a zero, its distance is NaN, and Haskell's `compare` answers GT for NaN
+    # either way -- the shortcut "ta <= tb, so dist a <= dist b" must not be taken for such hits.
+    assert gpu_fuzz.run_case(504773, kinds=9) is None
 
 
 def test_one_shot_call_spreads_over_devices(sqt, product_scene, oracle_scene, monkeypatch):

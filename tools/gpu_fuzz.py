@@ -28,8 +28,8 @@ THREADS = min(os.cpu_count() or 1, 16)
 BIG = "big" in sys.argv
 
 
-def make_scene(rng):
-    kind = rng.integers(0, 6)
+def make_scene(rng, kinds=10):
+    kind = rng.integers(0, kinds)            # `kinds` < 10 replays seeds found before the later kinds were added
     scale = float(rng.choice([1e-3, 1.0, 1.0, 1.0, 50.0, 1e4]))
     if kind == 0:      # soup
         n = int(rng.choice([3000, 8000, 20000] if BIG else [1, 2, 14, 15, 16, 40, 200, 1000, 3000]))
@@ -64,6 +64,34 @@ def make_scene(rng):
         d = rng.normal(0, 1, (n, 1, 3))
         t = rng.uniform(-1, 1, (n, 3, 1))
         v = a + d * t + rng.normal(0, float(rng.choice([0, 1e-6, 1e-3])), (n, 3, 3))
+    elif kind == 6:    # height-field strip: long thin leaves, grazing rays, shared vertices
+        k = int(rng.integers(4, 40))
+        xs, ys = np.meshgrid(np.linspace(-2, 2, k), np.linspace(-2, 2, k), indexing="ij")
+        zs = 0.3 * np.sin(3 * xs + rng.uniform(0, 6)) * np.cos(2 * ys) + rng.normal(0, 0.02, xs.shape)
+        p = np.stack([xs, ys, zs], -1)
+        q = [np.stack([p[:-1, :-1], p[1:, :-1], p[:-1, 1:]], 2).reshape(-1, 3, 3), np.stack([p[1:, :-1], p[1:, 1:], p[:-1, 1:]], 2).reshape(-1, 3, 3)]
+        lamp = np.array([[[-1, -1, 1.5], [1, -1, 1.5], [0, 1, 1.5]]])
+        v = np.concatenate(q + [lamp])
+    elif kind == 7:    # mirror room: every path runs to the bounce limit, mirror rays of mirror rays
+        r = 2.0
+        q = []
+        for ax in range(3):
+            for sgn in (-r, r):
+                a, b = [i for i in range(3) if i != ax]
+                p = np.zeros((4, 3)); p[:, ax] = sgn
+                p[:, a] = [-r, r, r, -r]; p[:, b] = [-r, -r, r, r]
+                q += [p[[0, 1, 2]], p[[0, 2, 3]]]
+        n = int(rng.integers(0, 60))
+        v = np.concatenate([np.array(q), rng.uniform(-1.5, 1.5, (n, 1, 3)) + rng.normal(0, 0.3, (n, 3, 3))])
+    elif kind == 8:    # magnitudes that overflow or underflow inside the ray-triangle test (inf, NaN, denormals)
+        n = int(rng.integers(15, 200))
+        v = rng.uniform(-1, 1, (n, 1, 3)) + rng.normal(0, 0.4, (n, 3, 3))
+        scale = float(rng.choice([1e-30, 1e-20, 1e12, 1e19, 3e37]))
+    elif kind == 9:    # a few NaN / infinite vertex coordinates (only the host BIH build accepts them)
+        n = int(rng.integers(15, 300))
+        v = rng.uniform(-2, 2, (n, 1, 3)) + rng.normal(0, 0.4, (n, 3, 3))
+        for _ in range(int(rng.integers(1, 6))):
+            v[rng.integers(0, n), rng.integers(0, 3), rng.integers(0, 3)] = rng.choice([np.nan, np.inf, -np.inf])
     else:              # axis-aligned thin plates through the origin (rays parallel to slab planes, zeros of both signs)
         n = int(rng.integers(16, 300))
         v = rng.uniform(-2, 2, (n, 3, 3))
@@ -77,6 +105,9 @@ def make_scene(rng):
     mats["surf"] = rng.uniform(0, 1, (nm, 3))
     mats["emissive"] = rng.choice([0.0, 0.0, 1.0, 20.0], nm)
     mats["emit"] = rng.uniform(0, 1, (nm, 3))
+    if kind == 7:
+        mats["reflective"] = 1.0                     # all mirrors ...
+        mats["reflective"][nm - 1] = 0.0             # ... but the light
     if rng.random() < 0.8:
         mats["emissive"][nm - 1] = 15.0              # most scenes have a light
     if rng.random() < 0.1:
@@ -128,9 +159,9 @@ def canon(a):
     return u
 
 
-def run_case(seed):
+def run_case(seed, kinds=10):
     rng = np.random.default_rng(seed)
-    v, mats, mat, scale = make_scene(rng)
+    v, mats, mat, scale = make_scene(rng, kinds)
     camt = make_camera(rng, scale)
     w, h = (int(rng.integers(40, 321)), int(rng.integers(40, 321))) if BIG else (int(rng.integers(1, 49)), int(rng.integers(1, 49)))
     spp = int(rng.choice([5, 16, 33, 64] if BIG else [1, 2, 3, 7, 16, 40]))
@@ -139,6 +170,12 @@ def run_case(seed):
     tris["v0"], tris["v1"], tris["v2"], tris["mat"] = v[:, 0], v[:, 1], v[:, 2], mat
     mesh = sqt.Mesh.from_arrays(tris, mats)
     on_device = bool(rng.random() < 0.5)
+    if on_device and not np.isfinite(v).all():
+        try:
+            sqt.BIH(mesh, device=0)
+            return "the device BIH build accepted non-finite vertices"
+        except sqt.SquiglyError:
+            on_device = False
     bih = sqt.BIH(mesh, device=0 if on_device else None)
     ot = np.zeros(len(v), O.TRI_DTYPE)
     ot["a"], ot["b"], ot["c"] = v[:, 0], v[:, 1], v[:, 2]
