@@ -28,7 +28,7 @@ THREADS = min(os.cpu_count() or 1, 16)
 BIG = "big" in sys.argv
 
 
-def make_scene(rng, kinds=10):
+def make_scene(rng, kinds=11):
     kind = rng.integers(0, kinds)            # `kinds` < 10 replays seeds found before the later kinds were added
     scale = float(rng.choice([1e-3, 1.0, 1.0, 1.0, 50.0, 1e4]))
     if kind == 0:      # soup
@@ -92,6 +92,10 @@ def make_scene(rng, kinds=10):
         v = rng.uniform(-2, 2, (n, 1, 3)) + rng.normal(0, 0.4, (n, 3, 3))
         for _ in range(int(rng.integers(1, 6))):
             v[rng.integers(0, n), rng.integers(0, 3), rng.integers(0, 3)] = rng.choice([np.nan, np.inf, -np.inf])
+    elif kind == 10:   # many identical triangles: terminal leaves of 32..200 (beyond what a packed leaf reference holds)
+        base = rng.uniform(-1.5, 1.5, (int(rng.integers(1, 5)), 3, 3))
+        v = np.concatenate([np.repeat(base[i:i + 1], int(rng.integers(20, 200)), 0) for i in range(len(base))] +
+                           [rng.uniform(-2, 2, (int(rng.integers(0, 40)), 3, 3))])
     else:              # axis-aligned thin plates through the origin (rays parallel to slab planes, zeros of both signs)
         n = int(rng.integers(16, 300))
         v = rng.uniform(-2, 2, (n, 3, 3))
@@ -110,11 +114,22 @@ def make_scene(rng, kinds=10):
         mats["reflective"][nm - 1] = 0.0             # ... but the light
     if rng.random() < 0.8:
         mats["emissive"][nm - 1] = 15.0              # most scenes have a light
+    if rng.random() < 0.3:
+        mats["surf"][nm - 1] = 0.0                   # a black surface (like the reference's lamp): absorbs every nested ray
+    if rng.random() < 0.1:
+        mats["surf"][0] = [0.0, -0.0, 0.0]           # a zero with its sign bit set is "negative" to the shortcut test
+    if rng.random() < 0.1:
+        mats["reflective"][0] = float(rng.choice([2.0, -1.0, np.nan, 0.5]))
     if rng.random() < 0.1:
         mats["surf"][0, 0] = -0.5                    # negative component: the exact `== 0` shortcuts are off
     if rng.random() < 0.05:
         mats["emit"][0, 1] = np.inf                  # non-finite material: the emitter cull is off
     mat = rng.integers(0, nm, len(v))
+    if rng.random() < 0.15 and len(v) > 70:          # around the 64-emitter limit of the last-bounce emitter test
+        mat[:] = rng.integers(0, max(nm - 1, 1), len(v))
+        mats["emissive"][: nm - 1] = 0.0
+        mats["emissive"][nm - 1] = 9.0
+        mat[rng.choice(len(v), int(rng.choice([1, 63, 64, 65])), replace=False)] = nm - 1
     return v, mats, mat, scale
 
 
@@ -159,7 +174,7 @@ def canon(a):
     return u
 
 
-def run_case(seed, kinds=10):
+def run_case(seed, kinds=11):
     rng = np.random.default_rng(seed)
     v, mats, mat, scale = make_scene(rng, kinds)
     camt = make_camera(rng, scale)
