@@ -1050,8 +1050,8 @@ extern "C" int sq_render_rows_device(sq_device_scene* s, const sq_camera* cam, i
     if (samples < 1 || w < 1 || h < 1) return sq_set_error("samples, width and height must be positive (got %d, %d, %d)", samples, w, h);
     const int32_t rows = sq_shard_rows(w, sh);
     if (rows < 0) return sq_set_error("bad shard {row_block=%d, shard=%d, n_shards=%d}", sh.row_block, sh.shard, sh.n_shards);
+    if (rows == 0) return 0;                    // an empty shard (more shards than row blocks) has nothing to render
     if (!d_avg && !d_rgb) return sq_set_error("no output buffer");
-    if (rows == 0) return 0;
     SQ_HIP(hipSetDevice(s->device));
     Frame F{};
     std::memcpy(F.cam_pos, cam->pos, sizeof F.cam_pos);

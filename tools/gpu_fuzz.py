@@ -216,6 +216,26 @@ def run_case(seed, kinds=11):
                 return f"avg differs in {bad}/{w * h} pixels (variant {variant}, cast {cast}, tris {len(v)}, spp {spp}, {w}x{h})"
             if not np.array_equal(r, o8):
                 return f"rgb8 differs (variant {variant})"
+        ds.set_option("variant", 2)
+        # a random shard of the same frame (interleaved row blocks) equals those rows of the whole frame
+        if rng.random() < 0.3 and w > 1:
+            rb, ns = int(rng.choice([1, 2, 3, 8, 16])), int(rng.integers(2, 6))
+            si = int(rng.integers(0, ns))
+            a, r = ds.render_rows(cam_p, spp, w, h, cast=cast, shard=(rb, si, ns))
+            torch.cuda.synchronize()
+            sh = sqt.Shard(rb, si, ns)
+            rows = [sqt.lib().sq_shard_global_row(j, sh) for j in range(a.shape[0])]
+            if not np.array_equal(canon(a.cpu().numpy()), canon(o[rows])) or not np.array_equal(r.cpu().numpy(), o8[rows]):
+                return f"shard ({rb},{si},{ns}) differs from the rows {rows[:4]}... of the whole frame"
+        # one row of a frame so tall that the sample seeds n*(x + y*w) pass 2^32 (and 2^40)
+        if rng.random() < 0.2:
+            wv = int(rng.choice([70000, 300000, 2000000]))
+            y = int(rng.integers(wv // 2, wv))
+            a, r = ds.render_rows(cam_p, spp, wv, h, cast=cast, shard=(1, y, wv))
+            torch.cuda.synchronize()
+            ov, ov8, _ = ob.render(cam_o, spp, wv, h, cast=cast, threads=1, rows=(y, y + 1))
+            if a.shape[0] != 1 or not np.array_equal(canon(a.cpu().numpy()), canon(ov)) or not np.array_equal(r.cpu().numpy(), ov8):
+                return f"row {y} of a {wv}-row frame differs (64-bit seeds)"
     finally:
         ds.close()
     return None
