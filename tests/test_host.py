@@ -183,3 +183,14 @@ def test_hit_distance_is_monotone_in_t():
             d1, d2 = dist(o, d, t1), dist(o, d, t2.astype(f))
         assert np.all(t2 >= t1)
         assert np.all(d2 >= d1), int((d2 < d1).sum())
+
+
+def test_loader_differential_fuzz_slice(sqt, O):
+    """A slice of tools/cpu_fuzz_loader.py: random .obj / .sq / camera texts from the reference grammar plus byte
+    mutations; the product loader and the oracle's accept and reject the same inputs and agree bit for bit."""
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import cpu_fuzz_loader
+    failures = [(seed, msg) for seed in range(5000, 7000) if (msg := cpu_fuzz_loader.run_case(seed))]
+    assert not failures, failures[:3]
