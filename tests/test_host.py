@@ -194,3 +194,34 @@ def test_loader_differential_fuzz_slice(sqt, O):
     import cpu_fuzz_loader
     failures = [(seed, msg) for seed in range(5000, 7000) if (msg := cpu_fuzz_loader.run_case(seed))]
     assert not failures, failures[:3]
+
+
+def test_bih_build_matches_oracle_on_fuzz_scenes(sqt, O):
+    """The host BIH build against the oracle's tree on the scene generators of tools/gpu_fuzz.py (ties, duplicates,
+    slivers, overflowing magnitudes, NaN / infinite coordinates, long identical-triangle leaves): every node and the
+    leaf order, bit for bit."""
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gpu_fuzz as F
+    for seed in range(3000, 3400):
+        rng = np.random.default_rng(seed)
+        v, mats, mat, _ = F.make_scene(rng)
+        tris = np.zeros(len(v), sqt._native.TRI_DTYPE)
+        tris["v0"], tris["v1"], tris["v2"], tris["mat"] = v[:, 0], v[:, 1], v[:, 2], mat
+        bih = sqt.BIH(sqt.Mesh.from_arrays(tris, mats))
+        ot = np.zeros(len(v), O.TRI_DTYPE)
+        ot["a"], ot["b"], ot["c"] = v[:, 0], v[:, 1], v[:, 2]
+        for f in ("reflective", "surf", "emissive", "emit"):
+            ot[f] = mats[f][mat]
+        ob = O.BIH(ot)
+        kind, lmax, rmin, cnt = ob.preorder()
+        nd = bih.nodes
+        br = kind != 3
+        u = lambda a: np.ascontiguousarray(a).view(np.uint32)
+        assert len(nd) == len(kind) and np.array_equal(nd["kind"] & 3, kind), seed
+        assert np.array_equal(u(nd["lmax"][br]), u(lmax[br])) and np.array_equal(u(nd["rmin"][br]), u(rmin[br])), seed
+        assert np.array_equal((nd["kind"] >> 2)[~br], cnt[~br]), seed
+        fl = ob.flatten()
+        assert np.array_equal(u(bih.tris["v0"]), u(fl["a"])) and np.array_equal(u(bih.tris["v1"]), u(fl["b"])) and np.array_equal(u(bih.tris["v2"]), u(fl["c"])), seed
+        assert np.array_equal(u(bih.bounds), u(np.array(ob.bounds(), np.float32).ravel())), seed
