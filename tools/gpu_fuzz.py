@@ -192,6 +192,12 @@ def run_case(seed, kinds=11):
         except sqt.SquiglyError:
             on_device = False
     bih = sqt.BIH(mesh, device=0 if on_device else None)
+    if on_device:                                       # the GPU build returns the host build's arrays, bit for bit
+        host = sqt.BIH(mesh)
+        raw = lambda a: np.ascontiguousarray(a).view(np.uint8)
+        if not (np.array_equal(raw(bih.nodes), raw(host.nodes)) and np.array_equal(raw(bih.tris), raw(host.tris))
+                and np.array_equal(raw(bih.bounds), raw(host.bounds))):
+            return "the device BIH build differs from the host build"
     ot = np.zeros(len(v), O.TRI_DTYPE)
     ot["a"], ot["b"], ot["c"] = v[:, 0], v[:, 1], v[:, 2]
     for f in ("reflective", "surf", "emissive", "emit"):
