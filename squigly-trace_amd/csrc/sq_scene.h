@@ -120,8 +120,7 @@ __device__ __forceinline__ float hit_dist(f3 o, f3 d, float t) {
 // A hit can carry t = +inf (f * dot overflows and still passes `t > eps`); its point has a NaN wherever the
 // direction has a zero, its distance is NaN, and the shortcut must not be taken.
 __device__ __forceinline__ bool dist_gt(f3 o, f3 d, float ta, float tb, bool finite_ray) {
-    const float inf = __builtin_inff();
-    if (finite_ray && ta < inf && tb < inf && !(ta > tb)) return false;
+    if (!(ta > tb) && tb < __builtin_inff() && finite_ray) return false;   // ta <= tb < inf: both finite
     return sq::cmp_gt(hit_dist(o, d, ta), hit_dist(o, d, tb));
 }
 
