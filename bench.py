@@ -60,7 +60,8 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and all_gather even with one rank (self-test)")
     args = ap.parse_args()
 
-    if not args.no_cpu and int(os.environ.get("RANK", "0")) == 0:
+    single = int(os.environ.get("WORLD_SIZE", "1")) == 1     # the CPU baseline (and the roofline it feeds) is an N=1 figure
+    if not args.no_cpu and single:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import pyoracle
         pyoracle.lib()                        # load (or build) the CPU checker before the GPU is initialised
@@ -131,7 +132,7 @@ def main():
                        "nonblack_pixels": int((frame.sum(-1) > 0).sum().item())},
         }
         cnt = None
-        if not args.no_cpu:
+        if not args.no_cpu and single:
             out["cpu_baseline"], cnt = cpu_baseline(w, h, args.spp, args.cpu_rows)
         if cnt is not None and launches:
             # Roofline of the dominant kernel (sq_trace_rays), HBM-bound by the north star's definition.
