@@ -45,7 +45,15 @@ constexpr int kBlock = 256;        // per-pixel / per-sample kernels
 constexpr int kTraceBlock = 512;   // persistent trace kernel, streaming form: 8 waves share one LDS copy of the top of the tree
 constexpr int kResidentBlock = 1024; // persistent trace kernel, resident form: one workgroup per CU owns the whole scene in LDS
 constexpr int kOneshotRowBlock = 8; // rows per block when a one-shot call shards a frame over devices
-constexpr int kChunk = 128;        // rays a wave reserves from the queue per atomic (multiple of 64)
+// Slots a wave reserves from the queue per atomic (multiple of 64).  Every reservation stalls the wave for the
+// atomic's round trip and then for the flag loads of the scan, and a sparse chunk (8 % of the slots are live at the
+// second bounce level) serves only part of the idle lanes: 64 -> 128 -> 256 measured 4340 -> 5110 -> 5520
+// Msamples/s on the headline frame.  256 is what a one-byte index within the chunk can address, which keeps the
+// per-wave list of live slots at 256 B of LDS.
+// The streaming form keeps 128: its rays are 5-10x longer, and on a frame of a few spp a wave that sits on 256 slots
+// at the end of the queue makes the tail longer than the stalls it saves (-7 % at 1920x1080@16).
+constexpr int kChunkResident = 256, kChunkStreaming = 128;
+using LiveT = uint8_t;             // a live slot's index within its chunk
 
 // ----------------------------------------------------------------------------------------------
 // Frame description shared by the kernels
@@ -363,7 +371,7 @@ __host__ __device__ inline TraceLds trace_lds_layout(int n_lds, bool resident, i
     L.refs = off;  off += resident ? al((uint32_t)n_lds * 8u) : 0u;
     L.verts = off; off += resident ? al((uint32_t)n_verts * 16u) : 0u;
     L.trix = off;  off += resident ? al((uint32_t)n_tris * 8u) : 0u;
-    L.live = off;  off += al((uint32_t)(block / 64) * kChunk * 2u);
+    L.live = off;  off += al((uint32_t)(block / 64) * (uint32_t)(resident ? kChunkResident : kChunkStreaming) * (uint32_t)sizeof(LiveT));
     L.stack = off; off += al((uint32_t)block * (uint32_t)stack_cap * (uint32_t)stack_elem);
     L.total = off;
     return L;
@@ -379,7 +387,8 @@ __global__ void __launch_bounds__(BLOCK) sq_trace_rays(const SceneView S, const 
     extern __shared__ float4 lds_raw[];
     char* lds = reinterpret_cast<char*>(lds_raw);
     const TraceLds L = trace_lds_layout(A.n_lds, RESIDENT, S.n_verts, S.n_tris, BLOCK, A.stack_cap, (int)sizeof(StackT));
-    SQ_LDS uint16_t* live = to_lds<uint16_t>(lds + L.live) + (threadIdx.x >> 6) * kChunk;   // this wave's list
+    constexpr int kChunk = RESIDENT ? kChunkResident : kChunkStreaming;
+    SQ_LDS LiveT* live = to_lds<LiveT>(lds + L.live) + (threadIdx.x >> 6) * kChunk;   // this wave's list
     SQ_LDS StackT* stk = to_lds<StackT>(lds + L.stack) + threadIdx.x;
     SQ_LDS v4f* lquads = to_lds<v4f>(lds + L.quads);
     using NodeSrc = typename std::conditional<RESIDENT, ResidentNodes, HybridNodes>::type;
@@ -432,7 +441,7 @@ __global__ void __launch_bounds__(BLOCK) sq_trace_rays(const SceneView S, const 
                 const long long idx = chunk_base + j * 64 + lane;
                 const bool alive = idx < n && A.org[idx].w >= 0.0f;
                 const unsigned long long am = __ballot(alive);
-                if (alive) live[list_len + __popcll(am & lt_mask)] = (uint16_t)(j * 64 + lane);
+                if (alive) live[list_len + __popcll(am & lt_mask)] = (LiveT)(j * 64 + lane);
                 list_len += __popcll(am);
             }
             n_traced += (unsigned long long)list_len;
