@@ -45,14 +45,14 @@ constexpr int kBlock = 256;        // per-pixel / per-sample kernels
 constexpr int kTraceBlock = 512;   // persistent trace kernel, streaming form: 8 waves share one LDS copy of the top of the tree
 constexpr int kResidentBlock = 1024; // persistent trace kernel, resident form: one workgroup per CU owns the whole scene in LDS
 constexpr int kOneshotRowBlock = 8; // rows per block when a one-shot call shards a frame over devices
-// Slots a wave reserves from the queue per atomic (multiple of 64).  Every reservation stalls the wave for the
-// atomic's round trip and then for the flag loads of the scan, and a sparse chunk (8 % of the slots are live at the
-// second bounce level) serves only part of the idle lanes: 64 -> 128 -> 256 measured 4340 -> 5110 -> 5520
-// Msamples/s on the headline frame.  256 is what a one-byte index within the chunk can address, which keeps the
-// per-wave list of live slots at 256 B of LDS.
+// Slots a wave reserves from the queue per atomic (multiple of 256 for the resident form).  Every reservation stalls
+// the wave for the atomic's round trip and then for the flag loads of the scan, and a sparse chunk (8 % of the slots
+// are live at the second bounce level) serves only part of the idle lanes: 64 -> 128 -> 256 -> 512 slots measured
+// 4340 -> 5110 -> 5520 -> 5605 Msamples/s on the headline frame (768: 5520).  The per-wave list of live slots holds
+// one byte per entry, an index within its 256-slot block (512 B of LDS per wave).
 // The streaming form keeps 128: its rays are 5-10x longer, and on a frame of a few spp a wave that sits on 256 slots
 // at the end of the queue makes the tail longer than the stalls it saves (-7 % at 1920x1080@16).
-constexpr int kChunkResident = 256, kChunkStreaming = 128;
+constexpr int kChunkResident = 512, kChunkStreaming = 128;
 using LiveT = uint8_t;             // a live slot's index within its chunk
 
 // ----------------------------------------------------------------------------------------------
@@ -429,6 +429,7 @@ __global__ void __launch_bounds__(BLOCK) sq_trace_rays(const SceneView S, const 
     unsigned int pl_unw = 0, pl_desc = 0, pl_tri = 0, pl_ref = 0;               // per lane (PROFILE)
     Trav T; T.mode = M_DONE; T.sp = 0; T.cur = 0; T.R.tri = -1; T.R.t = 0;
     T.o = T.d = T.df = sq::mk(0, 0, 0);
+    int sub_end[3] = { 0, 0, 0 };           // wave-uniform: list positions where the chunk's 2nd, 3rd, 4th 256-slot block start
     auto refill = [&](unsigned long long m, bool idle) {             // m = ballot(idle), wave-uniform
         while (!exhausted && list_pos == list_len) {                    // reserve and compact the next chunk
             int base = 0;
@@ -441,8 +442,9 @@ __global__ void __launch_bounds__(BLOCK) sq_trace_rays(const SceneView S, const 
                 const long long idx = chunk_base + j * 64 + lane;
                 const bool alive = idx < n && A.org[idx].w >= 0.0f;
                 const unsigned long long am = __ballot(alive);
-                if (alive) live[list_len + __popcll(am & lt_mask)] = (LiveT)(j * 64 + lane);
+                if (alive) live[list_len + __popcll(am & lt_mask)] = (LiveT)((j & 3) * 64 + lane);   // index within its 256-slot block
                 list_len += __popcll(am);
+                if ((j & 3) == 3 && j / 4 < 3) sub_end[j / 4] = list_len;
             }
             n_traced += (unsigned long long)list_len;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -455,7 +457,12 @@ __global__ void __launch_bounds__(BLOCK) sq_trace_rays(const SceneView S, const 
         if (PROFILE) ++pf_refill;
         if (idle && rank < avail) {
             if (PROFILE) ++pl_ref;
-            my_ray = chunk_base + live[list_pos + rank];
+            const int p = list_pos + rank;
+            int block = 0;
+            if (kChunk > 256) block += p >= sub_end[0];
+            if (kChunk > 512) block += p >= sub_end[1];
+            if (kChunk > 768) block += p >= sub_end[2];
+            my_ray = chunk_base + block * 256 + live[p];
             const float4 o = A.org[my_ray], d = A.dir[my_ray];
             trav_begin(T, S, root_ref, sq::mk(o.x, o.y, o.z), sq::mk(d.x, d.y, d.z));
         }
