@@ -99,7 +99,7 @@ int  sq_get_stats(sq_device_scene* s, uint64_t* out, int32_t n, int32_t reset);
  *                        288 GB; a frame with fewer samples allocates only what it needs)
  *   "resident"           1 = keep the whole scene in LDS when it fits (default), 0 = always stream
  *   "lds_node_kb"        streaming form: KB of LDS for the top of the tree (default 32)
- *   "straggler_lanes"    lanes still traversing when a wave turns to its leaves (default 6)
+ *   "straggler_lanes"    lanes still traversing when a wave turns to its leaves (default 8)
  *   "trace_blocks_per_cu" streaming form: workgroups per CU (0 = as many as LDS allows, up to 4)
  *   "timing"             1 = bracket the dominant kernel with hipEvents for sq_kernel_timing (default 0)
  *   "profile"            1 = lane-occupancy counters in sq_get_stats (slower)

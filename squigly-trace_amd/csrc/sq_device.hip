@@ -538,7 +538,7 @@ struct sq_device_scene {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
     double total_ms = 0; int64_t launches = 0;
     // options
-    int64_t opt_timing = 0, opt_variant = 2, opt_slots = 512ll << 20, opt_straggler = 6, opt_trace_blocks_per_cu = 0, opt_resident = 1, opt_profile = 0, opt_lds_node_kb = 32;
+    int64_t opt_timing = 0, opt_variant = 2, opt_slots = 512ll << 20, opt_straggler = 8, opt_trace_blocks_per_cu = 0, opt_resident = 1, opt_profile = 0, opt_lds_node_kb = 32;
     const char* last_kernel = "sq_trace_rays";
     // second stream of the overlapped schedule (launch_frame) and its event pool
     hipStream_t aux = nullptr; std::vector<hipEvent_t> events;
