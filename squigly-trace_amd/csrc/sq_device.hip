@@ -357,6 +357,7 @@ struct TraceArgs {
     const float4* org; const float4* dir; int2* hits;
     const int32_t* n_active; int32_t k_count; int32_t* head;
     int32_t n_lds; int32_t stack_cap; int32_t straggler_lanes;
+    int32_t chunk;               // slots per reservation: a multiple of 64, at most kChunkResident / kChunkStreaming
     unsigned long long* stats;   // [0] rays traced; PROFILE builds: [1] advance iterations (waves), [2] lanes unwinding,
                                  // [3] lanes descending, [4] leaf iterations (waves), [5] lanes testing a triangle,
                                  // [6] outer iterations (waves), [7] refill executions (waves), [8] lanes refilled
@@ -433,12 +434,14 @@ __global__ void __launch_bounds__(BLOCK) sq_trace_rays(const SceneView S, const 
     auto refill = [&](unsigned long long m, bool idle) {             // m = ballot(idle), wave-uniform
         while (!exhausted && list_pos == list_len) {                    // reserve and compact the next chunk
             int base = 0;
-            if (lane == 0) base = atomicAdd(A.head, kChunk);
+            if (lane == 0) base = atomicAdd(A.head, A.chunk);
             base = __builtin_amdgcn_readfirstlane(base);
             if (base >= n) { exhausted = true; break; }
             chunk_base = base; list_pos = 0; list_len = 0;
+            sub_end[0] = sub_end[1] = sub_end[2] = 0x7fffffff;          // blocks a short reservation does not reach
 #pragma unroll
             for (int j = 0; j < kChunk / 64; ++j) {
+                if (j * 64 >= A.chunk) break;
                 const long long idx = chunk_base + j * 64 + lane;
                 const bool alive = idx < n && A.org[idx].w >= 0.0f;
                 const unsigned long long am = __ballot(alive);
@@ -962,7 +965,11 @@ int launch_frame(sq_device_scene* s, const Frame& F, hipStream_t stream) {
     if (tr_lds > 64 * 1024) SQ_HIP(hipFuncSetAttribute(trace_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tr_lds));
     const int aux_blocks = s->n_cu * (int)(s->opt_aux_blocks_per_cu ? s->opt_aux_blocks_per_cu : 8);
     auto launch_trace = [&](const Work& W, int kc, int level) -> int {
-        TraceArgs A{ W.org, W.dir, W.hit, W.n_active, kc, W.head[level], n_lds, stack_cap, (int32_t)s->opt_straggler, W.stats };
+        // a launch with few slots (the per-pixel mirror rays) takes small reservations, or only a few waves get any
+        const int max_chunk = resident ? kChunkResident : kChunkStreaming;
+        const int64_t per_wave = pixels * (int64_t)kc / std::max(1, trace_blocks * (trace_threads / 64));
+        const int chunk = (int)std::min<int64_t>(max_chunk, std::max<int64_t>(64, (per_wave / 8) / 64 * 64));
+        TraceArgs A{ W.org, W.dir, W.hit, W.n_active, kc, W.head[level], n_lds, stack_cap, (int32_t)s->opt_straggler, chunk, W.stats };
         return timed([&] {
             void* kargs[] = { (void*)&S, (void*)&A };
             (void)hipLaunchKernel(trace_fn, dim3(trace_blocks), dim3(trace_threads), kargs, tr_lds, stream);
