@@ -7,9 +7,9 @@ import torch
 data = os.path.join(ROOT, "data")
 bih = sqt.BIH(sqt.Mesh.from_obj(os.path.join(data, "scene.obj"), data)); cam = sqt.load_camera(os.path.join(data, "camera"))
 ds = sqt.DeviceScene(bih, 0); ds.enable_timing()
-w, h, n = 1920, 1080, 64
+w, h, n = 1920, 1080, 256
 for res in (1, 0):
-    for strag in (6,):
+    for strag in (8,):
         ds.set_option("resident", res); ds.set_option("profile", 1); ds.set_option("straggler_lanes", strag)
         ds.render_rows(cam, n, w, h); torch.cuda.synchronize(); ds.stats(reset=True)
         ds.render_rows(cam, n, w, h); torch.cuda.synchronize()
