@@ -256,38 +256,49 @@ __global__ void __launch_bounds__(kBlock) sq_mirror1_store(const Work W) {
 __global__ void __launch_bounds__(kBlock) sq_shade1(const SceneView S, const Frame F, const Work W, int k_count) {
     const int A = *W.n_active;
     const unsigned total = (unsigned)A * (unsigned)k_count;
-    for (unsigned sid = blockIdx.x * kBlock + threadIdx.x; sid < total; sid += gridDim.x * kBlock) {
-        const float4 org = W.org[sid];
+    // The kernel waits on memory four fifths of its time, so everything a slot can need is requested up front, one
+    // level of dependent loads at a time, and the first level of the NEXT slot is requested before this one is worked on.
+    struct First { float4 org, dir; int2 hit; uint2 r; int a, tri0; };
+    auto first = [&](unsigned sid) {
+        First f;
+        f.org = W.org[sid]; f.dir = W.dir[sid]; f.hit = W.hit[sid]; f.r = W.rng12[sid];
+        f.a = (int)(sid % (unsigned)A); f.tri0 = W.px_tri0[f.a];
+        return f;
+    };
+    const unsigned stride = gridDim.x * kBlock;
+    unsigned sid = blockIdx.x * kBlock + threadIdx.x;
+    First nxt{};
+    if (sid < total) nxt = first(sid);
+    for (; sid < total; sid += stride) {
+        const First cur = nxt;
+        if (sid + stride < total) nxt = first(sid + stride);
+        const float4 org = cur.org, dir = cur.dir;
+        int2 hit = cur.hit;
+        const uint2 r = cur.r;
+        const int a = cur.a, tri0 = cur.tri0;
         if (org.w == kDead) continue;
         const bool mirrored = (org.w == kMirror);
-        int2 hit; f3 d1;
+        const Surface s0 = surface_of(S, tri0);                         // every finished path folds it in
+        f3 d1 = sq::mk(dir.x, dir.y, dir.z);
         if (mirrored) {                                                 // the pixel's mirror ray and its hit
-            const int a = (int)(sid % (unsigned)A);
             const Pixel0 P = load_pixel0(S, F, W, a);
             d1 = mirror_dir(P.d0, P.s0);
             hit = make_int2(__float_as_int(W.px_mt[a]), W.px_mtri[a]);
-        } else {
-            const float4 dir = W.dir[sid];
-            d1 = sq::mk(dir.x, dir.y, dir.z);
-            hit = W.hit[sid];
         }
         const int tri1 = hit.y;
         if (tri1 < 0) {                                                 // raytrace ... 1 = black
-            const Surface s0 = surface_of(S, W.px_tri0[sid % (unsigned)A]);
             store_rad(W, sid, s0.surf * sq::mk(0, 0, 0) + s0.emit);
             W.org[sid].w = kDead;
             continue;
         }
         const Surface s1 = surface_of(S, tri1);
         if (absorbs(S, s1)) {
-            const Surface s0 = surface_of(S, W.px_tri0[sid % (unsigned)A]);
             const f3 L1 = s1.surf * sq::mk(0, 0, 0) + s1.emit;
             store_rad(W, sid, s0.surf * L1 + s0.emit);
             W.org[sid].w = kDead;
             continue;
         }
         const f3 p1 = sq::mk(org.x, org.y, org.z) + sq::scale(__int_as_float(hit.x), d1);
-        const uint2 r = W.rng12[sid];
         const f3 d2 = bounce_dir(d1, s1, r.x, r.y);                     // gen advanced by one: x = u = p(n1), v = p(n2)
         // Ray 2 is the last one: all it contributes is L2 = s2*0 + e2, the emission of whatever it hits
         // (src/Lib.hs:129,135-137).  Whatever the traversal returns is a triangle that mollerTrumbore accepted
@@ -303,7 +314,6 @@ __global__ void __launch_bounds__(kBlock) sq_shade1(const SceneView S, const Fra
                 may_reach = moller_trumbore(p1, d2, sq::mk(tp[0], tp[1], tp[2]), sq::mk(tp[3], tp[4], tp[5]), sq::mk(tp[6], tp[7], tp[8]), t_unused);
             }
             if (!may_reach) {
-                const Surface s0 = surface_of(S, W.px_tri0[sid % (unsigned)A]);
                 const f3 L1 = s1.surf * sq::mk(0, 0, 0) + s1.emit;
                 store_rad(W, sid, s0.surf * L1 + s0.emit);
                 W.org[sid].w = kDead;
@@ -533,7 +543,7 @@ __global__ void sq_debug_kernel(int op, const void* a, const void* b, long long 
 struct sq_device_scene {
     int device = 0;
     SceneView view{};
-    void *d_branches = nullptr, *d_leaves = nullptr, *d_tris = nullptr, *d_mats = nullptr, *d_verts = nullptr, *d_trix = nullptr, *d_rbranch = nullptr, *d_emitters = nullptr, *d_tri_mat = nullptr;
+    void *d_branches = nullptr, *d_leaves = nullptr, *d_tris = nullptr, *d_mats = nullptr, *d_verts = nullptr, *d_trix = nullptr, *d_rbranch = nullptr, *d_emitters = nullptr, *d_tri_mat = nullptr, *d_surfs = nullptr;
     int height = 0; bool small_index = false; int n_cu = 256;
     // workspace (grow-only)
     Work work{}; void* d_work = nullptr; size_t work_bytes = 0; int64_t work_pixels = 0, work_slots = 0;
@@ -646,6 +656,7 @@ extern "C" int sq_scene_upload(const sq_scene* sc, int32_t device, sq_device_sce
         for (int c = 0; c < 3; ++c) { d.v0[c] = t.v0[c]; d.e1[c] = t.v1[c] - t.v0[c]; d.e2[c] = t.v2[c] - t.v0[c]; }
         tri_mat[(size_t)i] = t.mat;
     }
+    std::vector<DevSurf> sf((size_t)sc->n_tris);
     std::vector<DevMat> mt((size_t)sc->n_mats);
     bool nonneg = true;
     for (int32_t i = 0; i < sc->n_mats; ++i) {
@@ -653,6 +664,14 @@ extern "C" int sq_scene_upload(const sq_scene* sc, int32_t device, sq_device_sce
         mt[(size_t)i] = { m.reflective, m.surf[0], m.surf[1], m.surf[2], m.emissive, m.emit[0], m.emit[1], m.emit[2] };
         const float comp[8] = { m.reflective, m.surf[0], m.surf[1], m.surf[2], m.emissive, m.emit[0], m.emit[1], m.emit[2] };
         for (float c : comp) { uint32_t bits; std::memcpy(&bits, &c, 4); if ((bits >> 31) || !(c == c) || c > 3.0e38f) nonneg = false; }
+    }
+    for (int32_t i = 0; i < sc->n_tris; ++i) {                       // per-triangle shading record (surface_of)
+        const DevTri& d = tr[(size_t)i]; const sq_material& m = sc->mats[sc->tris[i].mat]; DevSurf& o = sf[(size_t)i];
+        const f3 nrm = sq::cross(sq::mk(d.e1[0], d.e1[1], d.e1[2]), sq::mk(d.e2[0], d.e2[1], d.e2[2]));
+        const f3 em = sq::scale(m.emissive, sq::mk(m.emit[0], m.emit[1], m.emit[2]));
+        o.n[0] = nrm.x; o.n[1] = nrm.y; o.n[2] = nrm.z; o.reflective = m.reflective;
+        o.surf[0] = m.surf[0]; o.surf[1] = m.surf[1]; o.surf[2] = m.surf[2]; o.pad0 = 0;
+        o.emit[0] = em.x; o.emit[1] = em.y; o.emit[2] = em.z; o.pad1 = 0;
     }
     // Indexed form for LDS residency: unique vertices (bitwise) + 16-bit indices, when they fit.
     std::vector<float> uverts; std::vector<uint16_t> trix;
@@ -750,7 +769,7 @@ extern "C" int sq_scene_upload(const sq_scene* sc, int32_t device, sq_device_sce
         return 0;
     };
     if (up(&s->d_branches, br.data(), br.size() * sizeof(DevBranch)) || up(&s->d_leaves, lf.data(), lf.size() * sizeof(DevLeaf)) ||
-        up(&s->d_tris, tr.data(), tr.size() * sizeof(DevTri)) || up(&s->d_tri_mat, tri_mat.data(), tri_mat.size() * sizeof(int32_t)) || up(&s->d_mats, mt.data(), mt.size() * sizeof(DevMat)) ||
+        up(&s->d_tris, tr.data(), tr.size() * sizeof(DevTri)) || up(&s->d_tri_mat, tri_mat.data(), tri_mat.size() * sizeof(int32_t)) || up(&s->d_surfs, sf.data(), sf.size() * sizeof(DevSurf)) || up(&s->d_mats, mt.data(), mt.size() * sizeof(DevMat)) ||
         up(&s->d_verts, uverts.data(), uverts.size() * sizeof(float)) || up(&s->d_trix, trix.data(), trix.size() * sizeof(uint16_t)) ||
         up(&s->d_rbranch, rbranch.data(), rbranch.size() * sizeof(uint32_t)) ||
         up(&s->d_emitters, emitters.data(), emitters.size() * sizeof(int32_t))) {
@@ -759,7 +778,7 @@ extern "C" int sq_scene_upload(const sq_scene* sc, int32_t device, sq_device_sce
     }
     SceneView& v = s->view;
     v.branches = (const float4*)s->d_branches; v.leaves = (const int2*)s->d_leaves;
-    v.tris = (const float*)s->d_tris; v.tri_mat = (const int32_t*)s->d_tri_mat; v.mats = (const float4*)s->d_mats;
+    v.tris = (const float*)s->d_tris; v.tri_mat = (const int32_t*)s->d_tri_mat; v.mats = (const float4*)s->d_mats; v.surfs = (const float4*)s->d_surfs;
     for (int c = 0; c < 3; ++c) { v.root_lo[c] = sc->root.lo[c]; v.root_hi[c] = sc->root.hi[c]; }
     v.root_ref = root_ref; v.packed_leaves = packed_leaves ? 1 : 0;
     v.n_branches = nb; v.n_leaves = nl; v.n_tris = sc->n_tris; v.n_mats = sc->n_mats;
@@ -816,7 +835,7 @@ extern "C" void sq_scene_free(sq_device_scene* s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
     for (auto& p : s->pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
-    (void)hipFree(s->d_branches); (void)hipFree(s->d_leaves); (void)hipFree(s->d_tris); (void)hipFree(s->d_mats); (void)hipFree(s->d_verts); (void)hipFree(s->d_trix); (void)hipFree(s->d_rbranch); (void)hipFree(s->d_emitters); (void)hipFree(s->d_tri_mat);
+    (void)hipFree(s->d_branches); (void)hipFree(s->d_leaves); (void)hipFree(s->d_tris); (void)hipFree(s->d_mats); (void)hipFree(s->d_verts); (void)hipFree(s->d_trix); (void)hipFree(s->d_rbranch); (void)hipFree(s->d_emitters); (void)hipFree(s->d_tri_mat); (void)hipFree(s->d_surfs);
     if (s->d_work) cache_give(s->device, s->d_work, s->work_bytes);
     for (hipEvent_t e : s->events) (void)hipEventDestroy(e);
     if (s->aux) (void)hipStreamDestroy(s->aux);

@@ -34,6 +34,11 @@ struct DevTri {             // 36 B: v0 | e1 = v1 - v0 | e2 = v2 - v0 (same roun
     float e2[3];
 };
 struct DevMat { float reflective, sr, sg, sb, emissive, er, eg, eb; };   // 32 B
+struct DevSurf {            // 48 B, three quads: everything shading needs from a hit triangle behind ONE index
+    float n[3], reflective;     // normal = e1 x e2 (src/Geometry.hs:79-80) | Material.reflective
+    float surf[3], pad0;        // surfColor
+    float emit[3], pad1;        // emissive *^ emitColor (src/Lib.hs:136), the same fp32 products as on the device
+};
 
 struct SceneView {
     const float4* branches;   // 3 quads per branch
@@ -41,6 +46,7 @@ struct SceneView {
     const float* tris;        // 9 floats per triangle (DevTri)
     const int32_t* tri_mat;   // material index per triangle
     const float4* mats;       // 2 quads per material
+    const float4* surfs;      // 3 quads per triangle (DevSurf): normal and material values, one dependent load instead of three
     float root_lo[3], root_hi[3];
     uint32_t root_ref;
     int32_t packed_leaves;    // 1: a leaf reference is kLeafBit | count << 24 | first (count <= 31, < 2^24 triangles), no table lookup
@@ -129,13 +135,12 @@ struct Surface {            // what shading needs from a hit triangle
     float reflective; f3 surf; f3 emit;   // emit = emissive *^ emitColor (src/Lib.hs:136)
 };
 __device__ __forceinline__ Surface surface_of(const SceneView& S, int tri) {
-    const float* t = S.tris + 9 * (size_t)tri;
-    const int m = S.tri_mat[tri];
-    const float4 m0 = S.mats[2 * m], m1 = S.mats[2 * m + 1];
+    const float4* q = S.surfs + 3 * (size_t)tri;
+    const float4 a = q[0], b = q[1], c = q[2];
     Surface s;
-    s.n = sq::cross(sq::mk(t[3], t[4], t[5]), sq::mk(t[6], t[7], t[8]));
-    s.reflective = m0.x; s.surf = sq::mk(m0.y, m0.z, m0.w);
-    s.emit = sq::scale(m1.x, sq::mk(m1.y, m1.z, m1.w));
+    s.n = sq::mk(a.x, a.y, a.z); s.reflective = a.w;
+    s.surf = sq::mk(b.x, b.y, b.z);
+    s.emit = sq::mk(c.x, c.y, c.z);
     return s;
 }
 
