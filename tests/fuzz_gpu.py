@@ -2,7 +2,7 @@
 path against the CPU oracle, bit for bit (fp32 `avg` and RGB8).  Prints one line per mismatch with the seed
 that reproduces it, and a summary.  Checker use of the oracle only (like tests/).
 
-    python tools/gpu_fuzz.py [seconds=240] [first_seed=0] [big]
+    python tests/fuzz_gpu.py [seconds=240] [first_seed=0] [big]
 
 `big`: frames up to 320 x 320 at up to 64 spp, scenes up to 20 000 triangles (the streaming kernel form), and a
 small sample-slot budget so that a frame takes several batches.

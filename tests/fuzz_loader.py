@@ -3,7 +3,7 @@ sq_camera_from_text) against the oracle's independent C restatement of src/Obj.h
 the reference grammar plus random mutations.  Both must accept and reject the same byte strings, and produce the
 same triangles, materials and camera matrices bit for bit.
 
-    python tools/cpu_fuzz_loader.py [seconds=60] [first_seed=0]
+    python tests/fuzz_loader.py [seconds=60] [first_seed=0]
 """
 import importlib
 import os

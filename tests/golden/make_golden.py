@@ -6,7 +6,7 @@ the oracle restatement; they pin the GPU path and guard the oracle against regre
 example_png_patches.json is derived from the reference's own rendered artefact
 (/root/reference/render/example.png) when that file is present.
 
-    python tools/make_golden.py
+    python tests/golden/make_golden.py
 """
 import hashlib
 import json
@@ -15,7 +15,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import pyoracle as O  # noqa: E402
 

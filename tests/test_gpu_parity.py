@@ -397,17 +397,15 @@ def test_random_soups_with_mirrors_and_emitters(sqt, O, seed, n_emit):
 
 
 def test_randomised_campaign(sqt, O):
-    """A slice of tools/gpu_fuzz.py (random scenes x cameras x frame shapes, both kernel forms, host- and
+    """A slice of tests/fuzz_gpu.py (random scenes x cameras x frame shapes, both kernel forms, host- and
     device-built trees): every case bit-equal to the oracle.  The full campaign is run by hand on the GPU box."""
-    import sys
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
-    import gpu_fuzz
-    failures = [(seed, msg) for seed in range(1000, 1400) if (msg := gpu_fuzz.run_case(seed))]
+    import fuzz_gpu
+    failures = [(seed, msg) for seed in range(1000, 1400) if (msg := fuzz_gpu.run_case(seed))]
     assert not failures, failures[:5]
     # Found by the campaign: coordinates around 1e19 make `f * dot e2 q` overflow, the hit has t = +inf, its point
     # has a NaN where the direction has a zero, its distance is NaN, and Haskell's `compare` answers GT for NaN
     # either way -- the shortcut "ta <= tb, so dist a <= dist b" must not be taken for such hits.
-    assert gpu_fuzz.run_case(504773, kinds=9) is None
+    assert fuzz_gpu.run_case(504773, kinds=9) is None
 
 
 def test_one_shot_call_spreads_over_devices(sqt, product_scene, oracle_scene, monkeypatch):

@@ -157,6 +157,11 @@ def test_product_does_not_touch_the_oracle():
                 assert "/root/reference" not in text
     ldd = subprocess.check_output(["ldd", os.path.join(pkg, "libsquigly_hip.so")]).decode()
     assert "oracle" not in ldd
+    # the measurement aids under tools/ stay away from it too: checker scripts live under tests/
+    for f in os.listdir(os.path.join(ROOT, "tools")):
+        if f.endswith((".py", ".sh")):
+            text = open(os.path.join(ROOT, "tools", f), errors="replace").read()
+            assert "pyoracle" not in text and "sqo_" not in text, f
 
 
 def test_hit_distance_is_monotone_in_t():
@@ -186,24 +191,18 @@ def test_hit_distance_is_monotone_in_t():
 
 
 def test_loader_differential_fuzz_slice(sqt, O):
-    """A slice of tools/cpu_fuzz_loader.py: random .obj / .sq / camera texts from the reference grammar plus byte
+    """A slice of tests/fuzz_loader.py: random .obj / .sq / camera texts from the reference grammar plus byte
     mutations; the product loader and the oracle's accept and reject the same inputs and agree bit for bit."""
-    import sys
-    from conftest import ROOT
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
-    import cpu_fuzz_loader
-    failures = [(seed, msg) for seed in range(5000, 7000) if (msg := cpu_fuzz_loader.run_case(seed))]
+    import fuzz_loader
+    failures = [(seed, msg) for seed in range(5000, 7000) if (msg := fuzz_loader.run_case(seed))]
     assert not failures, failures[:3]
 
 
 def test_bih_build_matches_oracle_on_fuzz_scenes(sqt, O):
-    """The host BIH build against the oracle's tree on the scene generators of tools/gpu_fuzz.py (ties, duplicates,
+    """The host BIH build against the oracle's tree on the scene generators of tests/fuzz_gpu.py (ties, duplicates,
     slivers, overflowing magnitudes, NaN / infinite coordinates, long identical-triangle leaves): every node and the
     leaf order, bit for bit."""
-    import sys
-    from conftest import ROOT
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
-    import gpu_fuzz as F
+    import fuzz_gpu as F
     for seed in range(3000, 3400):
         rng = np.random.default_rng(seed)
         v, mats, mat, _ = F.make_scene(rng)
