@@ -99,7 +99,12 @@ int  sq_get_stats(sq_device_scene* s, uint64_t* out, int32_t n, int32_t reset);
  *                        288 GB; a frame with fewer samples allocates only what it needs)
  *   "resident"           1 = keep the whole scene in LDS when it fits (default), 0 = always stream
  *   "lds_node_kb"        streaming form: KB of LDS for the top of the tree (default 32)
- *   "straggler_lanes"    lanes still traversing when a wave turns to its leaves (default 8)
+ *   "pool"               1 = pooled trace kernel (default): a wave tests the triangles of all its open leaves as a pool of
+ *                        (ray, triangle) pairs spread over its 64 lanes; 0 = every lane walks its own leaf
+ *   "refill_min"         pooled kernel: idle lanes a wave collects before it fetches new rays (default 12)
+ *   "flush_min"          pooled kernel: a trailing part-filled window of pairs runs at once from this many pairs on,
+ *                        otherwise it waits one iteration for more (default 40)
+ *   "straggler_lanes"    pool = 0: lanes still traversing when a wave turns to its leaves (default 8)
  *   "trace_blocks_per_cu" streaming form: workgroups per CU (0 = as many as LDS allows, up to 4)
  *   "timing"             1 = bracket the dominant kernel with hipEvents for sq_kernel_timing (default 0)
  *   "profile"            1 = lane-occupancy counters in sq_get_stats (slower)

@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsquigly_hip.so")
+# SQ_LIB_PATH: development aid, loads an experimental build of the same library (build.py --out=...) for A/B timing
+LIB_PATH = os.environ.get("SQ_LIB_PATH") or os.path.join(_HERE, "libsquigly_hip.so")
 
 # numpy mirrors of the C structs
 NODE_DTYPE = np.dtype([("kind", "<i4"), ("lmax", "<f4"), ("rmin", "<f4"), ("link", "<i4")])

@@ -43,7 +43,11 @@ def stale():
 CLI = os.path.join(HERE, "bin", "squigly-trace")
 
 
-def build(force=False, extra=()):
+def build(force=False, extra=(), out=None):
+    """out: build an experimental variant (extra -D flags) beside the product library; SQ_LIB_PATH selects it at load time."""
+    if out is not None:
+        subprocess.check_call([hipcc()] + FLAGS + list(extra) + ["-x", "hip"] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", out])
+        return out
     if not force and not stale() and os.path.exists(CLI):
         return OUT
     cmd = [hipcc()] + FLAGS + list(extra) + ["-x", "hip"] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", OUT]
@@ -57,4 +61,6 @@ def build(force=False, extra=()):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, extra=[a for a in sys.argv[1:] if a.startswith("-R") or a.startswith("-save")]))
+    outs = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--out=")]
+    print(build(force="--force" in sys.argv, extra=[a for a in sys.argv[1:] if a[:2] in ("-R", "-D") or a.startswith("-save")],
+                out=os.path.join(HERE, outs[0]) if outs else None))

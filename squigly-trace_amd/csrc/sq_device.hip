@@ -54,6 +54,11 @@ constexpr int kOneshotRowBlock = 8; // rows per block when a one-shot call shard
 // at the end of the queue makes the tail longer than the stalls it saves (-7 % at 1920x1080@16).
 constexpr int kChunkResident = 512, kChunkStreaming = 128;
 using LiveT = uint8_t;             // a live slot's index within its chunk
+#ifndef SQ_POOL_KW
+#define SQ_POOL_KW 1
+#endif
+constexpr int kStatSlots = 32;            // sq_get_stats
+constexpr int kPoolWindows = SQ_POOL_KW;   // pooled trace kernel: pair windows a wave works on at a time
 
 // ----------------------------------------------------------------------------------------------
 // Frame description shared by the kernels
@@ -368,21 +373,26 @@ struct TraceArgs {
     const int32_t* n_active; int32_t k_count; int32_t* head;
     int32_t n_lds; int32_t stack_cap; int32_t straggler_lanes;
     int32_t chunk;               // slots per reservation: a multiple of 64, at most kChunkResident / kChunkStreaming
+    int32_t refill_min;          // pooled form: idle lanes a wave collects before it fetches new rays for them
+    int32_t flush_min;           // pooled form: a trailing part-filled window of the pair pool is run at once from this many pairs on
     unsigned long long* stats;   // [0] rays traced; PROFILE builds: [1] advance iterations (waves), [2] lanes unwinding,
                                  // [3] lanes descending, [4] leaf iterations (waves), [5] lanes testing a triangle,
                                  // [6] outer iterations (waves), [7] refill executions (waves), [8] lanes refilled
+                                 // pooled form: [1] iterations (waves), [2] lanes unwinding, [3] lanes descending,
+                                 // [4] pair windows (waves), [5] pairs tested, [6] hits folded, [7] refill executions, [8] lanes refilled
 };
 // LDS carve-up of the trace kernel (bytes, all 16-B aligned), shared by host and device.
-struct TraceLds { uint32_t quads, refs, verts, trix, live, stack, total; };
+struct TraceLds { uint32_t quads, refs, verts, trix, live, tab, stack, total; };
 __host__ __device__ inline TraceLds trace_lds_layout(int n_lds, bool resident, int n_verts, int n_tris,
-                                                     int block, int stack_cap, int stack_elem) {
+                                                     int block, int stack_cap, int stack_elem, bool pool) {
     auto al = [](uint32_t b) { return (b + 15u) & ~15u; };
     TraceLds L; uint32_t off = 0;
+    L.verts = off; off += resident ? al((uint32_t)n_verts * 16u) : 0u;     // first: a vertex's LDS address is its byte offset (ResidentTris)
     L.quads = off; off += al((uint32_t)n_lds * (resident ? 32u : 48u));   // resident: 2 quads per branch; streaming: 3
     L.refs = off;  off += resident ? al((uint32_t)n_lds * 8u) : 0u;
-    L.verts = off; off += resident ? al((uint32_t)n_verts * 16u) : 0u;
     L.trix = off;  off += resident ? al((uint32_t)n_tris * 8u) : 0u;
     L.live = off;  off += al((uint32_t)(block / 64) * (uint32_t)(resident ? kChunkResident : kChunkStreaming) * (uint32_t)sizeof(LiveT));
+    L.tab = off;   off += pool ? al((uint32_t)block * kPoolWindows) : 0u;   // pooled form: one byte per lane and window in flight
     L.stack = off; off += al((uint32_t)block * (uint32_t)stack_cap * (uint32_t)stack_elem);
     L.total = off;
     return L;
@@ -393,11 +403,11 @@ __device__ __forceinline__ int wave_max(int v) {
     for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
     return v;
 }
-template <typename StackT, bool RESIDENT, int BLOCK, bool PROFILE>
+template <typename StackT, bool RESIDENT, int BLOCK, bool PROFILE, bool POOL>
 __global__ void __launch_bounds__(BLOCK) sq_trace_rays(const SceneView S, const TraceArgs A) {
     extern __shared__ float4 lds_raw[];
     char* lds = reinterpret_cast<char*>(lds_raw);
-    const TraceLds L = trace_lds_layout(A.n_lds, RESIDENT, S.n_verts, S.n_tris, BLOCK, A.stack_cap, (int)sizeof(StackT));
+    const TraceLds L = trace_lds_layout(A.n_lds, RESIDENT, S.n_verts, S.n_tris, BLOCK, A.stack_cap, (int)sizeof(StackT), POOL);
     constexpr int kChunk = RESIDENT ? kChunkResident : kChunkStreaming;
     SQ_LDS LiveT* live = to_lds<LiveT>(lds + L.live) + (threadIdx.x >> 6) * kChunk;   // this wave's list
     SQ_LDS StackT* stk = to_lds<StackT>(lds + L.stack) + threadIdx.x;
@@ -417,9 +427,13 @@ __global__ void __launch_bounds__(BLOCK) sq_trace_rays(const SceneView S, const 
             lrefs[i] = v2i{ (int)r[8], (int)r[9] };
         }
         for (int i = threadIdx.x; i < S.n_verts; i += BLOCK) { const float4 v = S.verts4[i]; lv[i] = v4f{ v.x, v.y, v.z, v.w }; }
-        for (int i = threadIdx.x; i < S.n_tris; i += BLOCK) { const ushort4 t = S.trix[i]; lt[i] = v4us{ t.x, t.y, t.z, t.w }; }
+        for (int i = threadIdx.x; i < S.n_tris; i += BLOCK) {              // vertex indices become byte offsets into the vertex table
+            const ushort4 t = S.trix[i];
+            lt[i] = v4us{ (unsigned short)(t.x * 16u), (unsigned short)(t.y * 16u), (unsigned short)(t.z * 16u), t.w };
+        }
         N = ResidentNodes{ lquads, lrefs };
-        G = ResidentTris{ lv, lt };
+        G = ResidentTris{ lt };
+        if ((uintptr_t)lv != 0) __builtin_trap();                          // the kernel has no static LDS, so its dynamic LDS starts at address 0
         root_ref = S.rroot;
     } else {
         for (int i = threadIdx.x; i < 3 * A.n_lds; i += BLOCK) { const float4 q = S.branches[i]; lquads[i] = v4f{ q.x, q.y, q.z, q.w }; }
@@ -481,6 +495,135 @@ __global__ void __launch_bounds__(BLOCK) sq_trace_rays(const SceneView S, const 
         }
         list_pos += min(__popcll(m), avail);
     };
+    if constexpr (POOL) {
+        // Pooled form.  One iteration offers every lane one return (pop a frame), one branch step, and then tests the
+        // triangles of ALL leaves the wave's rays have open as a pool of (ray, triangle) pairs: the pairs are numbered
+        // by a prefix sum over the lanes' leaf sizes and pair p = 64*window + lane is tested by lane `lane`, whatever
+        // ray owns it (the owner's origin, direction and triangle offset come over the DPP/bpermute network).  So a
+        // leaf of 14 triangles beside leaves of 3 no longer holds 64 lanes for 14 rounds: the wave runs
+        // ceil(sum / 64) full-width rounds.  Accepted hits are folded into the owning lane's R in pair order, which is
+        // leaf order, with the very comparison of the one-lane leaf loop (minimumBy's rule, src/BIH.hs:105-109) --
+        // the arithmetic of mollerTrumbore does not depend on the lane that runs it.
+        constexpr int KW = kPoolWindows;
+        SQ_LDS uint8_t* tab = to_lds<uint8_t>(lds + L.tab) + (threadIdx.x >> 6) * (64 * KW);   // this wave's window-head tables
+        for (int k = 0; k < KW; ++k) tab[k * 64 + lane] = 0;
+        const int lane_tag = lane * 4 + 1;  // a lane's mark in the head table: non-zero, grows with the lane, and is its ds_bpermute address
+        int lf_first = 0, lf_cnt = 0;       // M_LEAFQ: the untested rest of this lane's open leaf
+        bool carry = false;                 // wave-uniform: the previous iteration left queued pairs untested
+        unsigned int pl_hit = 0, pl_hslow = 0;
+        TravProf prof{};
+        // PROFILE: wave time per section of the loop (s_memtime ticks = shader cycles; the stamps themselves cost ~10 %)
+        unsigned long long tsec[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, tlast = PROFILE ? __builtin_amdgcn_s_memtime() : 0;
+        auto stamp = [&](int sec) { if (PROFILE) { const unsigned long long now = __builtin_amdgcn_s_memtime(); tsec[sec] += now - tlast; tlast = now; } };
+        for (;;) {
+            if (PROFILE) ++pf_adv;
+            const bool idle = (T.mode == M_DONE);
+            if (idle && my_ray >= 0) { A.hits[my_ray] = make_int2(__float_as_int(T.R.t), T.R.tri); my_ray = -1; }
+            const unsigned long long m = __ballot(idle);
+            if (m) {
+                if (__popcll(m) >= A.refill_min || m == ~0ull) refill(m, idle);
+                if (exhausted && m == ~0ull) break;
+            }
+            stamp(0);
+            if (PROFILE) pl_unw += (T.mode == M_UNWIND);
+            if (T.mode == M_UNWIND) trav_unwind(T, N, G, stk, BLOCK, PROFILE ? &prof : nullptr);
+            stamp(1);
+            if (PROFILE) pl_desc += (T.mode == M_DESCEND);
+            if (T.mode == M_DESCEND) trav_descend(T, N, stk, BLOCK);
+            stamp(2);
+            if (T.mode == M_LEAF) {                                         // open the leaf (src/BIH.hs:105): Nothing so far
+                const int2 lf = G.leaf(T.cur);
+                lf_first = lf.x; lf_cnt = lf.y; T.R.tri = -1;
+                T.mode = lf.y > 0 ? M_LEAFQ : M_UNWIND;
+            }
+            const int c = (T.mode == M_LEAFQ) ? lf_cnt : 0;
+            if (__ballot(c > 0) == 0) continue;
+            const int incl = wave_scan_add(c);                              // pairs of lanes 0..lane
+            const int P = __builtin_amdgcn_readlane(incl, 63);              // pairs queued in the wave
+            const int start = incl - c;                                     // this lane's first pair
+            const int tb = lf_first - start;                                // triangle of pair p = p + tb
+            int nwin = P >> 6;
+            const int rem = P & 63;
+            const bool others = __ballot(T.mode == M_UNWIND || T.mode == M_DESCEND) != 0;
+            if (rem && (!others || carry || rem >= A.flush_min)) ++nwin;
+            stamp(3);
+            // KW windows per step: their LDS round trips (head table, owner pulls, index record, vertices) are issued
+            // together and waited for once, and the independent arithmetic of KW triangle tests interleaves.
+            for (int w0 = 0; w0 < nwin; w0 += KW) {
+                int own[KW], tri[KW]; f3 po[KW], pd[KW]; float t[KW]; bool hit[KW];
+                // who owns pair base + lane?  Every owner whose pairs reach into a window writes its lane number at the
+                // window position of its first pair there; a max-scan spreads it over the owner's run.
+#pragma unroll
+                for (int k = 0; k < KW; ++k) {
+                    const int base = (w0 + k) << 6;
+                    const int h = start - base;
+                    if (c > 0 && h < 64 && incl > base) tab[k * 64 + (h > 0 ? h : 0)] = (uint8_t)lane_tag;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int k = 0; k < KW; ++k) { own[k] = tab[k * 64 + lane]; tab[k * 64 + lane] = 0; }
+#pragma unroll
+                for (int k = 0; k < KW; ++k) own[k] = wave_scan_max(own[k]);
+#pragma unroll
+                for (int k = 0; k < KW; ++k) {
+                    const int src = own[k];                                 // ds_bpermute takes lane * 4 and ignores the two low bits
+                    const int p = ((w0 + k) << 6) + lane;
+                    tri[k] = p + lane_pull(tb, src);
+                    po[k] = sq::mk(lane_pull(T.o.x, src), lane_pull(T.o.y, src), lane_pull(T.o.z, src));
+                    pd[k] = sq::mk(lane_pull(T.d.x, src), lane_pull(T.d.y, src), lane_pull(T.d.z, src));
+                    hit[k] = p < P;                                         // so far: the pair exists
+                    if (!hit[k]) tri[k] = 0;                                // lanes past the last pair test triangle 0 and drop the answer
+                }
+                if (PROFILE) { t[0] = po[0].x + pd[0].x + __int_as_float(tri[0]); asm volatile("" :: "v"(t[0])); }   // the pulls have arrived
+                stamp(4);
+                f3 v0[KW], e1[KW], e2[KW];
+#pragma unroll
+                for (int k = 0; k < KW; ++k) if (k == 0 || w0 + k < nwin) G.get1(tri[k], v0[k], e1[k], e2[k]);
+#pragma unroll
+                for (int k = 0; k < KW; ++k) {
+                    if (k == 0 || w0 + k < nwin) { float tk; const bool ok = moller_trumbore_flat(po[k], pd[k], v0[k], e1[k], e2[k], tk); t[k] = tk; hit[k] = hit[k] & ok; }
+                    else { t[k] = 0.0f; hit[k] = false; }
+                }
+                stamp(5);
+#pragma unroll
+                for (int k = 0; k < KW; ++k) {
+                    unsigned long long hm = __ballot(hit[k]);
+                    if (PROFILE) pl_hit += hit[k];
+                    while (hm) {                                            // accepted hits in pair order
+                        const int l = __ffsll((long long)hm) - 1;
+                        hm &= hm - 1;
+                        const int so = __builtin_amdgcn_readlane(own[k], l);
+                        const float st = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t[k]), l));
+                        const int stri = __builtin_amdgcn_readlane(tri[k], l);
+                        if (PROFILE && lane_tag == so && T.R.tri >= 0 && !(!(T.R.t > st) && st < __builtin_inff() && T.safe)) ++pl_hslow;
+                        if (lane_tag == so && (T.R.tri < 0 || dist_gt(T.o, T.d, T.R.t, st, T.safe))) { T.R.t = st; T.R.tri = stri; }
+                    }
+                }
+                stamp(6);
+            }
+            const int done = min(P, nwin << 6);
+            if (PROFILE) { pf_leaf += nwin; pf_outer += done; }
+            if (c > 0) {
+                if (incl <= done) T.mode = M_UNWIND;                        // the Leaf equation is finished: R is its value
+                else if (start < done) { lf_first += done - start; lf_cnt = incl - done; }
+            }
+            carry = done < P;
+            stamp(7);
+        }
+        if (lane == 0) atomicAdd(&A.stats[0], n_traced);
+        if (PROFILE) {
+            if (lane == 0) { atomicAdd(&A.stats[1], pf_adv); atomicAdd(&A.stats[4], pf_leaf); atomicAdd(&A.stats[5], pf_outer); atomicAdd(&A.stats[7], pf_refill); }
+            atomicAdd(&A.stats[2], (unsigned long long)pl_unw); atomicAdd(&A.stats[3], (unsigned long long)pl_desc);
+            atomicAdd(&A.stats[6], (unsigned long long)pl_hit); atomicAdd(&A.stats[8], (unsigned long long)pl_ref);
+            atomicAdd(&A.stats[9], (unsigned long long)prof.combine); atomicAdd(&A.stats[10], (unsigned long long)prof.recompute_lanes);
+            atomicAdd(&A.stats[11], (unsigned long long)prof.recompute_waves); atomicAdd(&A.stats[12], (unsigned long long)prof.slowcmp_lanes);
+            atomicAdd(&A.stats[13], (unsigned long long)prof.slowcmp_waves); atomicAdd(&A.stats[14], (unsigned long long)pl_hslow);
+            if (lane == 0) for (int i = 0; i < 8; ++i) atomicAdd(&A.stats[16 + i], tsec[i]);
+        }
+        return;
+    }
     for (;;) {
         if (PROFILE) ++pf_outer;
         const bool idle = (T.mode == M_DONE);
@@ -556,6 +699,7 @@ struct sq_device_scene {
     // second stream of the overlapped schedule (launch_frame) and its event pool
     hipStream_t aux = nullptr; std::vector<hipEvent_t> events;
     int64_t opt_overlap = 0, opt_aux_blocks_per_cu = 0;
+    int64_t opt_pool = 1, opt_refill_min = 12, opt_flush_min = 40;
 };
 
 namespace {
@@ -872,7 +1016,7 @@ int ensure_workspace(sq_device_scene* s, int64_t pixels, int64_t slots) {
     for (;;) {
         off = 0;
         auto take = [&](size_t bytes) { size_t o = off; off += al(bytes); return o; };
-        o_cnt = take(128 * sizeof(int32_t)); o_stats = take(16 * sizeof(unsigned long long));
+        o_cnt = take(128 * sizeof(int32_t)); o_stats = take(kStatSlots * sizeof(unsigned long long));
         o_pix = take(pixels * 4); o_t0 = take(pixels * 4); o_tri0 = take(pixels * 4); o_sum = take(pixels * 12);
         o_mt = take(pixels * 4); o_mtri = take(pixels * 4);
         o_org = take(slots * 16); o_dir = take(slots * 16); o_hit = take(slots * 8); o_rng = take(slots * 8); o_rad = take(slots * 12);
@@ -889,7 +1033,7 @@ int ensure_workspace(sq_device_scene* s, int64_t pixels, int64_t slots) {
     int32_t* cnt = (int32_t*)(base + o_cnt);
     W.n_active = cnt; W.head[0] = cnt + 16; W.head[1] = cnt + 32;      // separate cache lines
     W.stats = (unsigned long long*)(base + o_stats);
-    if (hipMemset(W.stats, 0, 16 * sizeof(unsigned long long)) != hipSuccess) return sq_set_error("hipMemset failed");
+    if (hipMemset(W.stats, 0, kStatSlots * sizeof(unsigned long long)) != hipSuccess) return sq_set_error("hipMemset failed");
     W.px_pixel = (int32_t*)(base + o_pix); W.px_t0 = (float*)(base + o_t0); W.px_tri0 = (int32_t*)(base + o_tri0); W.px_sum = (float*)(base + o_sum);
     W.px_mt = (float*)(base + o_mt); W.px_mtri = (int32_t*)(base + o_mtri);
     W.org = (float4*)(base + o_org); W.dir = (float4*)(base + o_dir); W.hit = (int2*)(base + o_hit);
@@ -960,22 +1104,25 @@ int launch_frame(sq_device_scene* s, const Frame& F, hipStream_t stream) {
     // workgroup per CU, no global traffic except ray fetch and hit store.  Streaming form otherwise.
     const size_t lds_budget = 160 * 1024;
     bool resident = false;
+    const bool pool = s->opt_pool != 0;
     TraceLds L{};
     if (s->opt_resident && S.trix) {
-        L = trace_lds_layout(S.n_branches, true, S.n_verts, S.n_tris, kResidentBlock, stack_cap, (int)sizeof(StackT));
-        resident = L.total <= lds_budget;
+        L = trace_lds_layout(S.n_branches, true, S.n_verts, S.n_tris, kResidentBlock, stack_cap, (int)sizeof(StackT), pool);
+        resident = L.total <= lds_budget && S.n_verts <= 4096;         // vertex byte offsets are 16-bit (ResidentTris)
     }
     int n_lds = S.n_branches, trace_blocks = 0, trace_threads = 0;
     const void* trace_fn = nullptr;
     if (resident) {
-        trace_fn = s->opt_profile ? (const void*)sq_trace_rays<StackT, true, kResidentBlock, true> : (const void*)sq_trace_rays<StackT, true, kResidentBlock, false>;
+        trace_fn = pool ? (s->opt_profile ? (const void*)sq_trace_rays<StackT, true, kResidentBlock, true, true> : (const void*)sq_trace_rays<StackT, true, kResidentBlock, false, true>)
+                        : (s->opt_profile ? (const void*)sq_trace_rays<StackT, true, kResidentBlock, true, false> : (const void*)sq_trace_rays<StackT, true, kResidentBlock, false, false>);
         trace_blocks = s->n_cu; trace_threads = kResidentBlock;
     } else {
         const size_t max_node_bytes = (size_t)s->opt_lds_node_kb * 1024;     // top of the tree; the rest of LDS buys occupancy
         if ((size_t)n_lds * 48 > max_node_bytes) n_lds = (int)(max_node_bytes / 48);
-        L = trace_lds_layout(n_lds, false, S.n_verts, S.n_tris, kTraceBlock, stack_cap, (int)sizeof(StackT));
+        L = trace_lds_layout(n_lds, false, S.n_verts, S.n_tris, kTraceBlock, stack_cap, (int)sizeof(StackT), pool);
         if (L.total > lds_budget) return sq_set_error("BIH height %d needs %u B of LDS per workgroup (max %zu)", S.height, L.total, lds_budget);
-        trace_fn = s->opt_profile ? (const void*)sq_trace_rays<StackT, false, kTraceBlock, true> : (const void*)sq_trace_rays<StackT, false, kTraceBlock, false>;
+        trace_fn = pool ? (s->opt_profile ? (const void*)sq_trace_rays<StackT, false, kTraceBlock, true, true> : (const void*)sq_trace_rays<StackT, false, kTraceBlock, false, true>)
+                        : (s->opt_profile ? (const void*)sq_trace_rays<StackT, false, kTraceBlock, true, false> : (const void*)sq_trace_rays<StackT, false, kTraceBlock, false, false>);
         int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, lds_budget / L.total));
         if (s->opt_trace_blocks_per_cu > 0) per_cu = (int)s->opt_trace_blocks_per_cu;
         trace_blocks = s->n_cu * per_cu; trace_threads = kTraceBlock;
@@ -988,7 +1135,8 @@ int launch_frame(sq_device_scene* s, const Frame& F, hipStream_t stream) {
         const int max_chunk = resident ? kChunkResident : kChunkStreaming;
         const int64_t per_wave = pixels * (int64_t)kc / std::max(1, trace_blocks * (trace_threads / 64));
         const int chunk = (int)std::min<int64_t>(max_chunk, std::max<int64_t>(64, (per_wave / 8) / 64 * 64));
-        TraceArgs A{ W.org, W.dir, W.hit, W.n_active, kc, W.head[level], n_lds, stack_cap, (int32_t)s->opt_straggler, chunk, W.stats };
+        TraceArgs A{ W.org, W.dir, W.hit, W.n_active, kc, W.head[level], n_lds, stack_cap, (int32_t)s->opt_straggler, chunk,
+                     (int32_t)s->opt_refill_min, (int32_t)s->opt_flush_min, W.stats };
         return timed([&] {
             void* kargs[] = { (void*)&S, (void*)&A };
             (void)hipLaunchKernel(trace_fn, dim3(trace_blocks), dim3(trace_threads), kargs, tr_lds, stream);
@@ -1127,13 +1275,13 @@ extern "C" void sq_kernel_timing_reset(sq_device_scene* s) {
     s->pending.clear(); s->total_ms = 0; s->launches = 0;
 }
 extern "C" int sq_get_stats(sq_device_scene* s, uint64_t* out, int32_t n, int32_t reset) {
-    if (!s || !out || n < 0 || n > 16) return sq_set_error("bad argument");
+    if (!s || !out || n < 0 || n > kStatSlots) return sq_set_error("bad argument");
     for (int i = 0; i < n; ++i) out[i] = 0;
     if (!s->d_work) return 0;
     SQ_HIP(hipSetDevice(s->device));
     SQ_HIP(hipDeviceSynchronize());
     SQ_HIP(hipMemcpy(out, s->work.stats, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost));
-    if (reset) SQ_HIP(hipMemset(s->work.stats, 0, 16 * sizeof(uint64_t)));
+    if (reset) SQ_HIP(hipMemset(s->work.stats, 0, kStatSlots * sizeof(uint64_t)));
     return 0;
 }
 extern "C" int sq_set_option(sq_device_scene* s, const char* key, int64_t value) {
@@ -1147,6 +1295,9 @@ extern "C" int sq_set_option(sq_device_scene* s, const char* key, int64_t value)
     if (!std::strcmp(key, "lds_node_kb")) { if (value < 0 || value > 128) return sq_set_error("lds_node_kb must be in 0..128"); s->opt_lds_node_kb = value; return 0; }
     if (!std::strcmp(key, "trace_blocks_per_cu")) { if (value < 0 || value > 8) return sq_set_error("trace_blocks_per_cu must be in 0..8"); s->opt_trace_blocks_per_cu = value; return 0; }
     if (!std::strcmp(key, "overlap")) { s->opt_overlap = value ? 1 : 0; return 0; }
+    if (!std::strcmp(key, "pool")) { s->opt_pool = value ? 1 : 0; return 0; }
+    if (!std::strcmp(key, "refill_min")) { if (value < 1 || value > 64) return sq_set_error("refill_min must be in 1..64"); s->opt_refill_min = value; return 0; }
+    if (!std::strcmp(key, "flush_min")) { if (value < 0 || value > 64) return sq_set_error("flush_min must be in 0..64"); s->opt_flush_min = value; return 0; }
     if (!std::strcmp(key, "aux_blocks_per_cu")) { if (value < 0 || value > 16) return sq_set_error("aux_blocks_per_cu must be in 0..16"); s->opt_aux_blocks_per_cu = value; return 0; }
     return sq_set_error("unknown option '%s'", key);
 }

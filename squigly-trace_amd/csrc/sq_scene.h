@@ -111,6 +111,24 @@ __device__ __forceinline__ bool moller_trumbore(f3 o, f3 d, f3 v0, f3 e1, f3 e2,
     t_out = t;
     return true;
 }
+// The same function without early exits: every value is produced by the same expression as above (a zero `a` makes
+// f infinite and the later values NaN or infinite, which the conjunction then rejects exactly as the first guard does).
+// For a full wave of unrelated (ray, triangle) pairs some lane nearly always reaches the last guard, so the exits
+// only cost branches there.
+__device__ __forceinline__ bool moller_trumbore_flat(f3 o, f3 d, f3 v0, f3 e1, f3 e2, float& t_out) {
+    const float eps = 0.0001f;
+    const f3 h = sq::cross(d, e2);
+    const float a = sq::dot(e1, h);
+    const float f = 1.0f / a;
+    const f3 s = o - v0;
+    const float u = f * sq::dot(s, h);
+    const f3 q = sq::cross(s, e1);
+    const float v = f * sq::dot(d, q);
+    const float t = f * sq::dot(e2, q);
+    const bool g1 = !(a > -eps && a < eps), g2 = !(u < 0 || u > 1), g3 = !(v < 0 || u + v > 1), g4 = t > eps;
+    t_out = t;
+    return g1 & g2 & g3 & g4;
+}
 // dist of an Intersection (src/Geometry.hs:134,141): norm ((o + t *^ d) - o), from the rounded hit point.
 __device__ __forceinline__ float hit_dist(f3 o, f3 d, float t) {
     const f3 p = o + sq::scale(t, d);
@@ -203,7 +221,8 @@ __device__ __forceinline__ f3 primary_dir(const float* rot, int w, int h, int y,
 // triangle: its t is recomputed with moller_trumbore (same bits); dist is always derived from t.
 // NodeSrc supplies branch quads (LDS-staged or global); StackT is uint16_t when indices fit 15 bits.
 // ----------------------------------------------------------------------------------------------
-enum : int { M_DESCEND = 0, M_LEAF = 1, M_UNWIND = 2, M_DONE = 3 };
+enum : int { M_DESCEND = 0, M_LEAF = 1, M_UNWIND = 2, M_DONE = 3,
+              M_LEAFQ = 4 };   // pooled leaf phase only: the leaf is open and its untested triangles are queued in the wave's pair pool
 
 template <typename StackT> struct StackTraits;
 template <> struct StackTraits<uint16_t> { static constexpr uint32_t flag = 0x8000u; };
@@ -297,6 +316,7 @@ struct GlobalTris {
             v0[k] = sq::mk(c[0], c[1], c[2]); e1[k] = sq::mk(c[3], c[4], c[5]); e2[k] = sq::mk(c[6], c[7], c[8]);
         }
     }
+    __device__ __forceinline__ void get1(int i, f3& v0, f3& e1, f3& e2) const { get_n<1>(i, &v0, &e1, &e2); }   // two 16-byte loads + one dword
     __device__ __forceinline__ int2 leaf(uint32_t ref) const {
         if (packed) return make_int2((int)(ref & 0xFFFFFFu), (int)((ref >> 24) & 31u));   // saves a dependent load per leaf visit
         return leaves[ref & ~kLeafBit];
@@ -304,23 +324,66 @@ struct GlobalTris {
 };
 struct ResidentTris {           // whole scene resident in LDS: 16-bit indexed triangles + unique vertices (16 B each)
     static constexpr bool kPairLoads = false;
-    const SQ_LDS v4f* verts; const SQ_LDS v4us* trix;
-    __device__ __forceinline__ void get(int i, f3& v0, f3& e1, f3& e2) const {
-        const v4us r = trix[i];
-        const v4f a = verts[r.x], b = verts[r.y], c = verts[r.z];
+    // The vertex table sits at the very start of the workgroup's LDS and a triangle record holds its three vertices as
+    // BYTE offsets into it (index * 16, which fits 16 bits for the <= 4096 vertices the resident form takes): a
+    // vertex address is the record field itself, no shift and no base add (integer VALU ops cost 4.2 cycles here
+    // against 2.5 for an fp32 multiply, tools/ubench/op_rate.hip).
+    const SQ_LDS v4us* trix;
+    __device__ __forceinline__ v4f vertex(unsigned off) const { return *reinterpret_cast<const SQ_LDS v4f*>((uintptr_t)off); }   // LDS address = offset (table at LDS address 0)
+    __device__ __forceinline__ void get(int i, f3& v0, f3& e1, f3& e2) const { get_indexed(trix[i], v0, e1, e2); }
+    __device__ __forceinline__ void get1(int i, f3& v0, f3& e1, f3& e2) const {    // three 16-bit reads: the offsets arrive zero-extended
+        const volatile SQ_LDS unsigned short* r = reinterpret_cast<const volatile SQ_LDS unsigned short*>(trix + i);   // volatile: keep them apart
+        const unsigned o0 = r[0], o1 = r[1], o2 = r[2];
+        const v4f a = vertex(o0), b = vertex(o1), c = vertex(o2);
         v0 = sq::mk(a.x, a.y, a.z);
         e1 = sq::mk(b.x, b.y, b.z) - v0;
         e2 = sq::mk(c.x, c.y, c.z) - v0;
     }
     __device__ __forceinline__ v4us index(int i) const { return trix[i]; }
     __device__ __forceinline__ void get_indexed(v4us r, f3& v0, f3& e1, f3& e2) const {
-        const v4f a = verts[r.x], b = verts[r.y], c = verts[r.z];
+        const v4f a = vertex(r.x), b = vertex(r.y), c = vertex(r.z);
         v0 = sq::mk(a.x, a.y, a.z);
         e1 = sq::mk(b.x, b.y, b.z) - v0;
         e2 = sq::mk(c.x, c.y, c.z) - v0;
     }
     __device__ __forceinline__ int2 leaf(uint32_t ref) const { return make_int2((int)(ref & 0xFFFFFFu), (int)((ref >> 24) & 31u)); }
 };
+
+// ---- wave64 prefix scans on the DPP network (gfx9 DPP: row_shr inside rows of 16 lanes, then row_bcast:15 and
+// row_bcast:31 carry a row's total into the rows above).  Six VALU instructions, no LDS.  EXEC must be all ones.
+__device__ __forceinline__ int wave_scan_add(int v) {       // inclusive
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+__device__ __forceinline__ int wave_scan_max(int v) {       // inclusive, values >= 0
+    // Written out: the compiler splits the two row_bcast steps into v_mov + v_mov_dpp + v_max.  A DPP read of a VGPR
+    // needs two wait states after the VALU write.  Lanes a step does not reach (bound_ctrl, row_mask) keep their value.
+    asm volatile(
+        "s_nop 1\n"
+        "v_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n s_nop 1\n"
+        "v_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n s_nop 1\n"
+        "v_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n s_nop 1\n"
+        "v_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n s_nop 1\n"
+        "v_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n s_nop 1\n"
+        "v_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
+        : "+v"(v));
+    return v;
+}
+__device__ __forceinline__ int lane_pull(int v, int byte_addr) { return __builtin_amdgcn_ds_bpermute(byte_addr, v); }
+__device__ __forceinline__ float lane_pull(float v, int byte_addr) { return __int_as_float(__builtin_amdgcn_ds_bpermute(byte_addr, __float_as_int(v))); }
+
+// PROFILE builds: how often the rare, expensive side paths of a return run.  `lanes` counts lanes, `waves` counts
+// executions (the first active lane of each execution adds one), which is what the SIMD pays for.
+struct TravProf { unsigned combine, recompute_lanes, recompute_waves, slowcmp_lanes, slowcmp_waves; };
+__device__ __forceinline__ bool first_active_lane() {
+    const unsigned long long m = __ballot(1);
+    return (m & ((1ull << (threadIdx.x & 63)) - 1ull)) == 0;
+}
 
 struct Trav {
     f3 o, d, df;
@@ -433,7 +496,7 @@ __device__ __forceinline__ void trav_leaf(Trav& T, const TriSrc& G) {
 
 // Return to the caller of the call that just produced R: pop one frame.  Pre: mode == M_UNWIND.
 template <typename NodeSrc, typename TriSrc, typename StackT>
-__device__ __forceinline__ void trav_unwind(Trav& T, const NodeSrc& N, const TriSrc& G, SQ_LDS StackT* stk, int stride) {
+__device__ __forceinline__ void trav_unwind(Trav& T, const NodeSrc& N, const TriSrc& G, SQ_LDS StackT* stk, int stride, TravProf* prof = nullptr) {
     constexpr uint32_t flag = StackTraits<StackT>::flag;
     if (T.sp == 0) { T.mode = M_DONE; return; }
     --T.sp;
@@ -441,12 +504,15 @@ __device__ __forceinline__ void trav_unwind(Trav& T, const NodeSrc& N, const Tri
     if (e & flag) {                                                     // minimumByMay over [near, far] (src/BIH.hs:115,120)
         const int32_t ntri = (int32_t)(e & ~flag);
         float nt = T.ct;
+        if (prof) ++prof->combine;
         if (T.csp != T.sp) {                                            // not the cached (newest) frame: same bits from MT
+            if (prof) { ++prof->recompute_lanes; prof->recompute_waves += first_active_lane(); }
             f3 v0, e1, e2;
             G.get(ntri, v0, e1, e2);
             (void)moller_trumbore(T.o, T.d, v0, e1, e2, nt);
         }
         T.csp = -1;
+        if (prof && T.R.tri >= 0 && !(!(nt > T.R.t) && T.R.t < __builtin_inff() && T.safe)) { ++prof->slowcmp_lanes; prof->slowcmp_waves += first_active_lane(); }
         if (T.R.tri < 0 || !dist_gt(T.o, T.d, nt, T.R.t, T.safe)) { T.R.t = nt; T.R.tri = ntri; }   // ties keep near
         return;
     }

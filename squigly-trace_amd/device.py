@@ -59,8 +59,8 @@ class DeviceScene:
 
     def stats(self, reset=False):
         """Cumulative trace-kernel statistics: [rays traced, profile counters...] (synchronises)."""
-        out = (C.c_uint64 * 16)()
-        N.check(N.lib().sq_get_stats(self._h, out, 16, int(reset)))
+        out = (C.c_uint64 * 32)()
+        N.check(N.lib().sq_get_stats(self._h, out, 32, int(reset)))
         return [int(v) for v in out]
 
     def reset_timing(self):
