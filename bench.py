@@ -1,19 +1,25 @@
 #!/usr/bin/env python3
-"""Headline benchmark: Msamples/s on data/scene.obj, 1920x1080 @ 256 spp per GPU (BASELINE.json configs[1]).
+"""Headline benchmark: Msamples/s on data/scene.obj, 1920x1080 @ 256 spp (BASELINE.json configs[1]).
 
-    python bench.py --gpus 1 --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --steps K --warmup W [--config c2|c4] [--scaling strong|weak]
 
-A step is one pass of the hot path over one frame: every pixel's `samples` paths are traced, accumulated
-in sample order and tonemapped (src/Lib.hs:68-137).  The scene is already resident in HBM when the timed
-region starts.  With N ranks the frame is 1080p at 256*N spp (per-GPU work fixed => weak scaling): rows
-are sharded in interleaved blocks of 8, each rank renders its rows on its GPU and one RCCL all_gather
-reassembles the RGB8 framebuffer inside the timed region.  Msamples/s does not depend on spp.
+With N > 1 and no WORLD_SIZE in the environment this process starts N rank processes itself (a
+`python -m torch.distributed.run` child, before anything here touches a GPU) and relays rank 0's JSON line;
+under torchrun (WORLD_SIZE set) it IS one of the ranks.  It exits non-zero if fewer than N devices are visible.
+
+A step is one pass of the hot path over one frame: every pixel's `samples` paths are traced, accumulated in
+sample order and tonemapped (src/Lib.hs:68-137).  The scene is already resident in HBM when the timed region
+starts.  With N ranks the SAME frame (strong scaling, the default: 1080p @ 256 spp in total) is cut into
+interleaved blocks of 8 rows, each rank renders its rows on its GPU, and one RCCL all_gather_into_tensor
+reassembles the RGB8 framebuffer inside the timed region.  `--scaling weak` renders the frame at 256*N spp instead
+(per-GPU work fixed).  `--config c4` is BASELINE.json configs[3]: 3840x2160 @ 1024 spp.
 """
 import argparse
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -21,6 +27,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+N_SIMD, CLOCK_HZ = 1024, 2.4e9   # 256 CUs x 4 SIMD-32, max clock (same guide)
+VALU_PEAK_TLANEOPS = N_SIMD * 32 * CLOCK_HZ / 1e12      # 78.6: one wave64 VALU instruction per 2 cycles per SIMD (= 157.3 TFLOP/s of FMAs)
+CONFIGS = {"c2": (1920, 1080, 256), "c4": (3840, 2160, 1024)}   # first number = image ROWS (src/Lib.hs:70-71)
 
 
 def alg_bytes(c, spp):
@@ -47,20 +56,104 @@ def cpu_baseline(w, h, spp, budget_rows):
             "sample": f"{rows} rows (every {step}th) of the {w}x{h} @ {spp} spp frame = {cnt['samples']} samples in {dt:.1f} s"}, cnt
 
 
+def load_profile(name):
+    path = os.path.join(ROOT, "profiles", name)
+    if os.path.exists(path):
+        with open(path) as f:
+            return json.load(f)
+    return None
+
+
+def launch_ranks(args):
+    """--gpus N without torchrun: start the N ranks as a child job and relay rank 0's line.  The parent makes no HIP
+    call (torch.cuda.device_count() only counts devices on this image) and never replaces itself."""
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but only {have} HIP device(s) are visible; refusing to report a "
+              f"{args.gpus}-GPU number from fewer devices", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0 or line is None:
+        print(f"bench.py: the {args.gpus}-rank job failed (rc {proc.returncode})", file=sys.stderr)
+        return proc.returncode or 1
+    print(line, flush=True)
+    return 0
+
+
+def time_other_config(sqt, torch, name, make, w, h, spp, traffic_key):
+    """One stand-in configuration on this GPU through the resident API, second frame timed (the first one allocates)."""
+    obj, sq, camt = make()
+    mesh = sqt.Mesh.from_text(obj, sq)
+    t = time.perf_counter(); bih = sqt.BIH(mesh, device=0 if len(mesh) >= 50000 else None); t_build = time.perf_counter() - t
+    cam = sqt.camera_from_text(camt)
+    ds = sqt.DeviceScene(bih, 0)
+    ds.enable_timing()
+    ds.render_rows(cam, spp, w, h, want_avg=False); torch.cuda.synchronize()
+    ds.reset_timing(); ds.stats(reset=True)
+    t = time.perf_counter(); ds.render_rows(cam, spp, w, h, want_avg=False); torch.cuda.synchronize(); dt = time.perf_counter() - t
+    kern_ms, launches, kname = ds.kernel_timing()
+    rays = ds.stats()[0]
+    ds.close()
+    out = {"workload": f"{name}: {len(mesh)} triangles, BIH height {bih.height}, {w}x{h} @ {spp} spp, one GPU",
+           "value": round(w * h * spp / dt / 1e6, 1), "unit": "Msamples/s", "ms_per_step": round(dt * 1e3, 1),
+           "bih_build_ms": round(t_build * 1e3, 1), "rays_traced": rays,
+           "kernel": kname, "kernel_ms_total": round(kern_ms * launches, 1), "launches": launches}
+    prof = load_profile("latest_other_configs.json")
+    if prof and traffic_key in prof and kern_ms > 0:
+        p = prof[traffic_key]      # per frame, sq_trace_rays launches: separate --pmc passes (tools/collect_profiles.sh)
+        traffic = p["hbm_bytes_per_frame"]
+        out["roofline"] = {"bound": "hbm", "achieved": round(traffic / (kern_ms * launches * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                           "unit": "GB/s", "frac": round(traffic / (kern_ms * launches * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                           "traffic": traffic,
+                           "what": "memory-side bytes of the trace launches of one frame (FETCH_SIZE x 2 + WRITE_SIZE, Infinity-Cache hits "
+                                   "included: the guide's counters cannot separate them) / their measured duration",
+                           "vmem_load_wave_instructions_per_ray": round(p["vmem_rd_per_frame"] / max(rays, 1), 2) if p.get("vmem_rd_per_frame") else None,
+                           "l2_hit_rate": p.get("l2_hit_rate")}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--width", type=int, default=1920)      # first dimension = image ROWS (src/Lib.hs:70-71)
-    ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--spp", type=int, default=256)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2", help="c2 = 1920x1080 @ 256 spp (headline), c4 = 3840x2160 @ 1024 spp")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="strong: the configuration's frame is shared by the ranks; weak: spp is multiplied by the rank count")
+    ap.add_argument("--width", type=int, default=0)         # overrides of the configuration (first dimension = image ROWS)
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--spp", type=int, default=0)
     ap.add_argument("--cpu-rows", type=int, default=96, help="rows of the frame timed on the CPU oracle")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and all_gather even with one rank (self-test)")
+    ap.add_argument("--no-other", action="store_true", help="skip the C3/C5 stand-in configurations (N = 1 only)")
+    ap.add_argument("--no-oneshot", action="store_true", help="skip the one-shot call's wall time (profiling runs: keeps the launch count per step)")
+    ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and gather even with one rank (self-test)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be positive")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
 
-    single = int(os.environ.get("WORLD_SIZE", "1")) == 1     # the CPU baseline (and the roofline it feeds) is an N=1 figure
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_env != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world_env}: the launcher and the flag disagree", file=sys.stderr)
+        sys.exit(2)
+    single = world_env == 1 and not args.force_dist          # CPU baseline, roofline and the other configurations are N = 1 figures
     if not args.no_cpu and single:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import pyoracle
@@ -71,27 +164,28 @@ def main():
     d = importlib.import_module("squigly-trace_amd.dist")
 
     rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if rank == 0:
-            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    if torch.cuda.device_count() <= local_rank:
+        print(f"bench.py: rank {rank} has no device {local_rank} ({torch.cuda.device_count()} visible)", file=sys.stderr)
+        sys.exit(2)
     torch.cuda.set_device(local_rank)
-    use_dist = world > 1 or args.force_dist
+    use_dist = world_env > 1 or args.force_dist
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    world = dist.get_world_size() if use_dist else 1          # the ranks RCCL actually connected
 
     data = os.path.join(ROOT, "data")
     bih = sqt.BIH(sqt.Mesh.from_obj(os.path.join(data, "scene.obj"), data))
     cam = sqt.load_camera(os.path.join(data, "camera"))
     scene = sqt.DeviceScene(bih, local_rank)                 # resident in HBM before the timed region
     scene.enable_timing()                                    # hipEvents around every sq_trace_rays launch, on its stream
-    w, h = args.width, args.height
-    spp = args.spp * world                                   # weak scaling: 256 spp of work per GPU
+    cw, ch, cspp = CONFIGS[args.config]
+    w, h, base_spp = args.width or cw, args.height or ch, args.spp or cspp
+    spp = base_spp * world if args.scaling == "weak" else base_spp
 
     def step():
         return d.render_frame(scene, cam, spp, w, h, want="rgb")
@@ -124,14 +218,16 @@ def main():
         out = {
             "metric": "Msamples/s (whole node) at 1080p/256spp on data/scene.obj",
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "data/scene.obj + data/scene.sq + data/camera (the reference's sample scene)",
-            "config": {"workload": f"data/scene.obj {w}x{h} @ {args.spp} spp per GPU "
-                                   f"(one {w}x{h} frame at {spp} spp, rows sharded over {world} GPU(s), RGB8 all_gather)",
+            "parity": "bit-identical to this repository's C restatement of the Haskell (oracle/); unpinned against a GHC build of the reference",
+            "config": {"workload": f"data/scene.obj {w}x{h} @ {spp} spp (BASELINE configs[{1 if args.config == 'c2' else 3}]"
+                                   f"{'' if (w, h, base_spp) == CONFIGS[args.config] else ', size overridden'}), "
+                                   f"rows sharded over {world} GPU(s) in blocks of {d.ROW_BLOCK}, RGB8 all_gather_into_tensor",
                        "samples_per_step": samples_per_step, "row_block": d.ROW_BLOCK,
                        "nonblack_pixels": int((frame.sum(-1) > 0).sum().item())},
         }
-        if single:
+        if single and not args.no_oneshot and args.config == "c2" and not (args.width or args.height or args.spp):
             # SURVEY 8(d) asks for the rate with the scene upload included as well: the one-shot drop-in call
             # (upload + workspace + render + copy back over PCIe), second call timed.  Reported beside `value`, never as it.
             sqt.render_rgb8(bih, cam, spp, (w, h))
@@ -142,37 +238,62 @@ def main():
                                     "what": "sq_render_rgb8: scene upload + render + 6.2 MB copy back, host buffers in and out"}
         cnt = None
         if not args.no_cpu and single:
-            out["cpu_baseline"], cnt = cpu_baseline(w, h, args.spp, args.cpu_rows)
-        if cnt is not None and launches:
-            # Roofline of the dominant kernel (sq_trace_rays), HBM-bound by the north star's definition.
-            # Algorithmic bytes are the REFERENCE algorithm's: per sample, from the oracle's visit
-            # counters on the CPU sample above, times the samples one step's trace launches serve on this rank,
-            # divided by the hipEvent-measured duration of those launches.
-            b = alg_bytes(cnt, args.spp)
+            out["cpu_baseline"], cnt = cpu_baseline(w, h, base_spp, args.cpu_rows)
+        if single and launches:
+            # Roofline of the dominant kernel, sq_trace_rays.  The 0.3 MB scene lives in LDS, so HBM is not what binds it
+            # (measured traffic is ~2 % of the HBM peak); the resource that binds is VALU issue.  VALU wave-instructions,
+            # active cycles and thread cycles come from a separate rocprofv3 --pmc pass of this same command
+            # (profiles/latest_pmc.json; the counts depend only on the workload), the duration is measured live here
+            # with hipEvents on the launch stream.
             launches_per_step = launches / args.steps
             trace_s_per_step = kern_ms * 1e-3 * launches_per_step
-            rank_samples = samples_per_step / world
-            achieved = b * rank_samples / trace_s_per_step / 1e9
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-            if os.path.exists(tpath):
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-            # Unit = one bounce ray; per-unit figure = the reference's bytes per bounce ray (oracle counters for
-            # rays at depth >= 1); units per launch = rays the launches actually dequeued (device counter).
             rays = stats[0] / args.steps
-            bytes_per_ray = (cnt["b_branch_visits"] * 16 + cnt["b_tri_tests"] * 40 + cnt["b_hits"] * 32) / max(cnt["b_rays"], 1)
-            achieved_rays = bytes_per_ray * rays / trace_s_per_step / 1e9
-            out["roofline"] = {"bound": "hbm", "achieved": round(achieved_rays, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(achieved_rays / HBM_PEAK_GBS, 4), "traffic": traffic,
-                               "kernel": kname, "kernel_ms": round(kern_ms, 3), "launches": launches,
-                               "launches_per_step": launches_per_step,
-                               "alg_bytes_per_ray": round(bytes_per_ray, 1), "rays_per_launch": int(rays / launches_per_step),
-                               "alg_bytes_per_sample_reference": round(b, 1),
-                               "achieved_reference_samples": round(achieved, 2),
-                               "note": "scene.obj (0.3 MB) is LDS/L2-resident: algorithmic bytes are served on chip, "
-                                       "so frac can exceed 1; measured HBM bytes are in `traffic`"}
+            pmc = load_profile("latest_pmc.json")
+            roof = {"kernel": kname, "kernel_ms": round(kern_ms, 3), "launches": launches, "launches_per_step": launches_per_step,
+                    "rays_per_launch": int(rays / launches_per_step)}
+            if pmc and pmc.get("workload") == [w, h, spp]:
+                insts, active, threads = pmc["SQ_INSTS_VALU"], pmc["SQ_ACTIVE_INST_VALU"], pmc["SQ_THREAD_CYCLES_VALU"]
+                lane_util = threads / (64.0 * active)
+                issue = insts / trace_s_per_step / (N_SIMD * CLOCK_HZ / 2)
+                achieved = insts * 64 * lane_util / trace_s_per_step / 1e12
+                traffic = (pmc["FETCH_SIZE_KB"] * 2 + pmc["WRITE_SIZE_KB"]) * 1024 / launches_per_step
+                roof.update({"bound": "valu", "achieved": round(achieved, 2), "peak": round(VALU_PEAK_TLANEOPS, 1), "unit": "Tlane-op/s",
+                             "frac": round(achieved / VALU_PEAK_TLANEOPS, 4),
+                             "valu_issue_frac": round(issue, 4), "valu_lane_utilisation": round(lane_util, 4),
+                             "valu_wave_instructions_per_launch": int(insts / launches_per_step),
+                             "traffic": int(traffic),
+                             "hbm": {"achieved": round(traffic / (kern_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": round(traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                             "note": "frac = valu_issue_frac x valu_lane_utilisation: busy VALU lanes / (1024 SIMDs x 32 lanes x 2.4 GHz). "
+                                     "Counters: profiles/latest_pmc.json (separate --pmc passes); duration: live hipEvents. "
+                                     "traffic = HBM-side bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE): ray fetch and hit store only."})
+            else:
+                roof.update({"bound": "valu", "achieved": None, "peak": round(VALU_PEAK_TLANEOPS, 1), "unit": "Tlane-op/s", "frac": None,
+                             "traffic": None, "note": "no profiles/latest_pmc.json for this workload"})
+            if cnt is not None:
+                # SURVEY §8(d)'s algorithmic bytes, kept for reference: they are served from LDS, not HBM, so they
+                # are not a roofline fraction.  Unit = one bounce ray (oracle counters for rays at depth >= 1).
+                bytes_per_ray = (cnt["b_branch_visits"] * 16 + cnt["b_tri_tests"] * 40 + cnt["b_hits"] * 32) / max(cnt["b_rays"], 1)
+                roof["algorithmic"] = {"bytes_per_ray": round(bytes_per_ray, 1),
+                                       "bytes_per_sample_reference": round(alg_bytes(cnt, base_spp), 1),
+                                       "GBps_for_rays_traced": round(bytes_per_ray * rays / trace_s_per_step / 1e9, 1),
+                                       "served_from": "LDS (scene resident per CU)"}
+            out["roofline"] = roof
+        if single and not args.no_other and args.config == "c2":
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import gen_scenes as G
+            scene.close()
+            scene = None
+            sqt.release_cached_memory()
+            out["other_configs"] = {
+                "c3": time_other_config(sqt, torch, "BASELINE configs[2] stand-in (procedural blob, no Stanford Bunny offline)",
+                                        lambda: G.blob_scene(6), 1920, 1080, 512, "c3"),
+                "c5": time_other_config(sqt, torch, "BASELINE configs[4] stand-in (jittered height-field)",
+                                        lambda: G.heightfield_scene(708), 1920, 1080, 256, "c5"),
+            }
         print(json.dumps(out), flush=True)
-    scene.close()
+    if scene is not None:
+        scene.close()
     if use_dist:
         dist.destroy_process_group()
 

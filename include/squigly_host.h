@@ -23,6 +23,10 @@ int32_t sq_mesh_num_materials(const sq_mesh* m);
 const sq_tri*      sq_mesh_tris(const sq_mesh* m);
 const sq_material* sq_mesh_materials(const sq_mesh* m);
 void sq_mesh_free(sq_mesh* m);
+/* What `--debug` prints while loading (src/Obj.hs:55-57): `print (head objs)` and `print mats`, in the text of Haskell's
+ * derived Show instances (records, lists, `show :: Float -> String`).  The strings belong to the mesh; both are empty
+ * for a mesh that did not come from .obj/.sq text, and *first_object is empty when the file has no object. */
+void sq_mesh_debug_show(const sq_mesh* m, const char** first_object, const char** materials);
 
 /* Obj.loadCamera (src/Obj.hs:60-70): "px py pz\nalpha beta gamma" -> position + rotMatrixRads. */
 int  sq_camera_from_file(const char* path, sq_camera* cam);

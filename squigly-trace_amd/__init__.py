@@ -13,6 +13,11 @@ def device_count() -> int:
     return lib().sq_device_count()
 
 
+def release_cached_memory() -> None:
+    """Hand the frame workspaces kept for the next scene back to the driver (sq_release_cached_memory)."""
+    lib().sq_release_cached_memory()
+
+
 def __getattr__(name):
     # torch is only needed for the resident-scene path
     if name in ("DeviceScene",):

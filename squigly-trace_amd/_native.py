@@ -96,6 +96,8 @@ def lib():
     L.sq_camera_from_text.argtypes = [C.c_char_p, sz, C.POINTER(Camera)]
     L.sq_rot_matrix_rads.argtypes = [C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float)]
     L.sq_rot_matrix_rads.restype = None
+    L.sq_mesh_debug_show.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p)]
+    L.sq_mesh_debug_show.restype = None
     L.sq_release_cached_memory.argtypes = []
     L.sq_release_cached_memory.restype = None
     L.sq_bih_build.argtypes = [vp, C.POINTER(vp)]
@@ -144,6 +146,6 @@ EXPORTED_SYMBOLS = [
     # include/squigly_host.h
     "sq_mesh_from_obj", "sq_mesh_from_text", "sq_mesh_from_arrays", "sq_mesh_num_tris",
     "sq_mesh_num_materials", "sq_mesh_tris", "sq_mesh_materials", "sq_mesh_free", "sq_camera_from_file",
-    "sq_camera_from_text", "sq_rot_matrix_rads", "sq_release_cached_memory", "sq_bih_build", "sq_bih_build_device", "sq_bih_scene", "sq_bih_height",
+    "sq_camera_from_text", "sq_rot_matrix_rads", "sq_release_cached_memory", "sq_mesh_debug_show", "sq_bih_build", "sq_bih_build_device", "sq_bih_scene", "sq_bih_height",
     "sq_bih_num_leaves", "sq_bih_longest_leaf", "sq_bih_free",
 ]

@@ -42,6 +42,10 @@ def main(argv=None):
                         cameraPath=a.camerapath, debug=a.debug, debugPath=a.debugpath, cast=a.cast)
     cam = load_camera(settings.cameraPath)                      # app/Main.hs:38
     mesh = Mesh.from_obj(settings.objPath, "./data")            # loadTris, app/Main.hs:58-61 + src/Obj.hs:52
+    if settings.debug:                                          # src/Obj.hs:55-57: print (head objs); print mats
+        first, mats = mesh.debug_show()
+        print(first)
+        print(mats)
     # loadBIH, app/Main.hs:63-75.  Both builds give the same arrays; the GPU one wins from a few 10^4 triangles up.
     bih = BIH(mesh, device=0 if (len(mesh) >= 50000 and lib().sq_device_count() > 0) else None)
     if settings.debug:

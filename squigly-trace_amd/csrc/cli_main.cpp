@@ -96,6 +96,11 @@ int main(int argc, char** argv) {
     if (sq_camera_from_file(camp.c_str(), &cam)) return fail("Failed to parse camera");        // app/Main.hs:38
     sq_mesh* mesh = nullptr;
     if (sq_mesh_from_obj(objp.c_str(), "./data", &mesh)) return fail("loading the scene");      // app/Main.hs:58-61
+    if (debug) {                                                                                 // src/Obj.hs:55-57: print (head objs); print mats
+        const char *first = "", *mats = "";
+        sq_mesh_debug_show(mesh, &first, &mats);
+        std::printf("%s\n%s\n", first, mats);
+    }
     sq_bih* bih = nullptr;
     // app/Main.hs:66.  Both builds give the same arrays; the GPU one wins from a few 10^4 triangles up.
     const bool on_gpu = sq_mesh_num_tris(mesh) >= 50000 && sq_device_count() > 0;

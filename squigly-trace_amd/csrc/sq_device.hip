@@ -809,6 +809,23 @@ extern "C" int sq_scene_upload(const sq_scene* sc, int32_t device, sq_device_sce
         const float comp[8] = { m.reflective, m.surf[0], m.surf[1], m.surf[2], m.emissive, m.emit[0], m.emit[1], m.emit[2] };
         for (float c : comp) { uint32_t bits; std::memcpy(&bits, &c, 4); if ((bits >> 31) || !(c == c) || c > 3.0e38f) nonneg = false; }
     }
+    // The s == 0 shortcuts (absorbs()) replace `0 * L` by +0, which is only the reference's value while the nested
+    // radiance L is finite (0 * inf = NaN, src/Lib.hs:135).  Components <= 3e38 do not bound the PRODUCTS: the emission
+    // `emissive *^ emitColor` (src/Lib.hs:136) and `surf * L + e` one level down can overflow.  L <= max_s * max_e + max_e
+    // with max_e the largest emission (as the fp32 product the kernels use) and max_s the largest surface component;
+    // the shortcuts stay on only if that bound, evaluated in double, is comfortably finite in fp32.
+    if (nonneg) {
+        double max_e = 0.0, max_s = 0.0;
+        for (int32_t i = 0; i < sc->n_mats; ++i) {
+            const sq_material& m = sc->mats[i];
+            for (int k = 0; k < 3; ++k) {
+                const float e = m.emissive * m.emit[k];
+                if (!(e - e == 0.0f)) nonneg = false;                    // the product itself is inf
+                max_e = std::max(max_e, (double)e); max_s = std::max(max_s, (double)m.surf[k]);
+            }
+        }
+        if (!(max_s * max_e + max_e <= 3.0e38)) nonneg = false;
+    }
     for (int32_t i = 0; i < sc->n_tris; ++i) {                       // per-triangle shading record (surface_of)
         const DevTri& d = tr[(size_t)i]; const sq_material& m = sc->mats[sc->tris[i].mat]; DevSurf& o = sf[(size_t)i];
         const f3 nrm = sq::cross(sq::mk(d.e1[0], d.e1[1], d.e1[2]), sq::mk(d.e2[0], d.e2[1], d.e2[2]));

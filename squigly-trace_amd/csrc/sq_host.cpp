@@ -10,6 +10,7 @@
 #include "sq_host_types.h"
 #include "sq_math.h"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -66,7 +67,7 @@ struct Scanner {
     }
 };
 
-struct ObjObject { std::string mtl; size_t face_begin, face_end; };
+struct ObjObject { std::string mtl; size_t face_begin, face_end, vert_end; };   // vert_end: vertices read up to and including this object
 struct ObjFile {
     std::string mtllib;
     std::vector<f3> verts;                 // all objects' vertices, concatenated (src/Obj.hs:76)
@@ -94,6 +95,7 @@ bool scan_obj(const char* text, size_t len, ObjFile& f) {
         if (sc.literal("usemtl")) { sq_set_error("obj: expected 'usemtl' at byte %zu", sc.i); return false; } // src/Obj.hs:123-124
         sc.skip_ws();
         ObjObject ob;
+        ob.vert_end = f.verts.size();
         if (!sc.word(ob.mtl)) return false;
         if (sc.peek() == 's') {                                                                             // optional parseS, src/Obj.hs:132-133
             size_t mark = sc.i;
@@ -144,6 +146,56 @@ bool scan_sq(const char* text, size_t len, std::vector<std::string>& names, std:
     return true;
 }
 
+// ---- Haskell's derived Show text, for --debug (src/Obj.hs:55-57) ----
+// show :: Float -> String (Numeric.showFloat): the shortest digits that identify the value; positional notation for
+// 0.1 <= |x| < 10^7, otherwise d.ddde<n>; always a digit on both sides of the point.
+std::string show_float(float x) {
+    if (x != x) return "NaN";
+    if (x - x != 0.0f) return x > 0 ? "Infinity" : "-Infinity";
+    std::string out;
+    uint32_t bits; std::memcpy(&bits, &x, 4);
+    if (bits >> 31) { out = "-"; x = -x; }
+    if (x == 0.0f) return out + "0.0";
+    char buf[48]; std::string digits; int e10 = 0;
+    for (int p = 1; p <= 9; ++p) {                      // shortest correctly rounded decimal that reads back as x
+        std::snprintf(buf, sizeof buf, "%.*e", p - 1, (double)x);
+        if (std::strtof(buf, nullptr) == x || p == 9) {
+            digits.clear();
+            const char* c = buf;
+            for (; *c && *c != 'e'; ++c) if (*c >= '0' && *c <= '9') digits.push_back(*c);
+            e10 = std::atoi(c + 1) + 1;                 // x = 0.d1d2... * 10^e10 (floatToDigits' convention)
+            break;
+        }
+    }
+    while (digits.size() > 1 && digits.back() == '0') digits.pop_back();
+    if (e10 < 0 || e10 > 7) {                           // exponent form (formatRealFloat FFGeneric: e < 0 || e > 7)
+        out += digits.substr(0, 1) + "." + (digits.size() > 1 ? digits.substr(1) : std::string("0")) + "e" + std::to_string(e10 - 1);
+        return out;
+    }
+    std::string ip = digits.substr(0, std::min<size_t>((size_t)e10, digits.size()));
+    ip.append((size_t)e10 - ip.size(), '0');
+    if (ip.empty()) ip = "0";
+    std::string fp = digits.size() > (size_t)e10 ? digits.substr((size_t)e10) : std::string("0");
+    return out + ip + "." + fp;
+}
+std::string show_v3(const float v[3]) {                 // V3 {_x = .., _y = .., _z = ..}  (src/V3.hs:5)
+    return "V3 {_x = " + show_float(v[0]) + ", _y = " + show_float(v[1]) + ", _z = " + show_float(v[2]) + "}";
+}
+std::string show_string(const std::string& t) {         // show :: String -> String
+    std::string o = "\"";
+    for (size_t i = 0; i < t.size(); ++i) {
+        const unsigned char c = (unsigned char)t[i];
+        if (c == '"') o += "\\\"";
+        else if (c == '\\') o += "\\\\";
+        else if (c >= 32 && c < 127) o.push_back((char)c);
+        else {
+            o += "\\" + std::to_string((int)c);
+            if (i + 1 < t.size() && t[i + 1] >= '0' && t[i + 1] <= '9') o += "\\&";
+        }
+    }
+    return o + "\"";
+}
+
 bool read_file(const char* path, std::string& out) {
     FILE* fp = std::fopen(path, "rb");
     if (!fp) { sq_set_error("cannot open '%s'", path); return false; }
@@ -163,6 +215,21 @@ extern "C" int sq_mesh_from_text(const char* obj_text, size_t obj_len, const cha
     if (!scan_sq(sq_text, sq_len, names, mats)) return 1;
     sq_mesh* m = new sq_mesh;
     m->mats = mats;
+    if (!f.objects.empty()) {                           // print (head objs): Object {verts = [..], mtl = "..", faces = [..]}  (src/Obj.hs:88-94)
+        const ObjObject& ob = f.objects[0];
+        std::string t = "Object {verts = [";
+        for (size_t i = 0; i < ob.vert_end; ++i) { const float v[3] = { f.verts[i].x, f.verts[i].y, f.verts[i].z }; t += (i ? "," : "") + show_v3(v); }
+        t += "], mtl = " + show_string(ob.mtl) + ", faces = [";
+        for (size_t fi = ob.face_begin; fi < ob.face_end; ++fi)
+            t += std::string(fi > ob.face_begin ? "," : "") + "Face {_i1 = " + std::to_string(f.faces[3 * fi]) + ", _i2 = " + std::to_string(f.faces[3 * fi + 1]) +
+                 ", _i3 = " + std::to_string(f.faces[3 * fi + 2]) + "}";
+        m->show_first_object = t + "]}";
+    }
+    m->show_materials = "[";                            // print mats :: [(String, Material)]  (src/Color.hs:78-83)
+    for (size_t i = 0; i < names.size(); ++i)
+        m->show_materials += std::string(i ? "," : "") + "(" + show_string(names[i]) + ",Mat {reflective = " + show_float(mats[i].reflective) + ", surfColor = " +
+                             show_v3(mats[i].surf) + ", emissive = " + show_float(mats[i].emissive) + ", emitColor = " + show_v3(mats[i].emit) + "})";
+    m->show_materials += "]";
     // makeScene (src/Obj.hs:73-77): every (object, material) pair with equal names, objects outermost.
     for (const ObjObject& ob : f.objects)
         for (size_t mi = 0; mi < names.size(); ++mi) {
@@ -218,6 +285,10 @@ extern "C" int32_t sq_mesh_num_materials(const sq_mesh* m) { return (int32_t)m->
 extern "C" const sq_tri* sq_mesh_tris(const sq_mesh* m) { return m->tris.data(); }
 extern "C" const sq_material* sq_mesh_materials(const sq_mesh* m) { return m->mats.data(); }
 extern "C" void sq_mesh_free(sq_mesh* m) { delete m; }
+extern "C" void sq_mesh_debug_show(const sq_mesh* m, const char** first_object, const char** materials) {
+    if (first_object) *first_object = m ? m->show_first_object.c_str() : "";
+    if (materials) *materials = m ? m->show_materials.c_str() : "";
+}
 
 // ----------------------------------------------------------------------------------------------
 // Camera (src/Obj.hs:60-70, src/Geometry.hs:90-107)

@@ -2,6 +2,7 @@
 // host build (sq_host.cpp) and the GPU build (sq_bih_device.hip).
 #pragma once
 #include <cstdint>
+#include <string>
 #include <vector>
 
 #include "../../include/squigly_host.h"
@@ -9,6 +10,7 @@
 struct sq_mesh {
     std::vector<sq_tri> tris;          // loader order (src/Obj.hs:73-86)
     std::vector<sq_material> mats;
+    std::string show_first_object, show_materials;   // `print (head objs)` / `print mats` of --debug (src/Obj.hs:55-57); empty unless loaded from text
 };
 
 struct sq_bih {

@@ -8,8 +8,6 @@ This plays the role of massiv's `Par` scheduler (src/Lib.hs:73) one level up.
 import torch
 import torch.distributed as dist
 
-from . import _native as N
-
 ROW_BLOCK = 8   # rows per block: small enough to balance the very non-uniform image, large enough for whole tiles
 
 
@@ -21,32 +19,67 @@ def shard_rows(w, row_block, rank, world):
     return rows
 
 
+class FramePlan:
+    """Everything about one (w, row_block, world) partition that does not change from frame to frame.
+
+    A frame is gathered as ONE all_gather_into_tensor of equal buffers [mx, h, C] (mx = the largest shard; shorter
+    shards are padded) into [world * mx, h, C], followed by ONE index_select that de-interleaves the rows:
+    frame[y] = gathered[src[y]] with src precomputed on the device.  Nothing here runs per frame on the host.
+    """
+
+    def __init__(self, w, row_block, world, device):
+        self.w, self.row_block, self.world = w, row_block, world
+        shards = [shard_rows(w, row_block, r, world) for r in range(world)]
+        self.counts = [len(s) for s in shards]
+        self.mx = max(self.counts) if world else 0
+        src = torch.empty(w, dtype=torch.long)
+        for r, rows in enumerate(shards):
+            if rows:
+                src[torch.tensor(rows, dtype=torch.long)] = r * self.mx + torch.arange(len(rows), dtype=torch.long)
+        self.src = src.to(device)
+        self._buffers = {}
+
+    def buffers(self, h, c, dtype, device):
+        """(send [mx, h, c], gathered [world * mx, h, c]): allocated once per frame shape."""
+        key = (h, c, dtype)
+        if key not in self._buffers:
+            self._buffers[key] = (torch.zeros((self.mx, h, c), dtype=dtype, device=device),
+                                  torch.empty((self.world * self.mx, h, c), dtype=dtype, device=device))
+        return self._buffers[key]
+
+
+_plans = {}
+
+
+def plan_for(w, row_block, world, device):
+    key = (w, row_block, world, str(device))
+    if key not in _plans:
+        _plans[key] = FramePlan(w, row_block, world, device)
+    return _plans[key]
+
+
 def gather_frame(local, w, row_block=ROW_BLOCK, group=None):
     """all_gather the per-rank compact row buffers [rows_r, h, C] and de-interleave into [w, h, C].
 
     Ranks may own different row counts (last block ragged): buffers are padded to the largest.
     Every rank returns the full frame.
     """
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
-    h, c = local.shape[1], local.shape[2]
-    counts = [len(shard_rows(w, row_block, r, world)) for r in range(world)]
-    assert local.shape[0] == counts[rank], (local.shape, counts, rank)
-    if world == 1 and not dist.is_initialized():
+    initialised = dist.is_initialized()
+    world = dist.get_world_size(group) if initialised else 1
+    rank = dist.get_rank(group) if initialised else 0
+    if not initialised:
+        assert local.shape[0] == w, (local.shape, w)
         return local
-    mx = max(counts)
-    padded = local
-    if local.shape[0] < mx:
-        padded = torch.zeros((mx, h, c), dtype=local.dtype, device=local.device)
-        padded[: local.shape[0]] = local
-    parts = [torch.empty_like(padded) for _ in range(world)]
-    dist.all_gather(parts, padded.contiguous(), group=group)
-    frame = torch.empty((w, h, c), dtype=local.dtype, device=local.device)
-    for r in range(world):
-        idx = torch.tensor(shard_rows(w, row_block, r, world), dtype=torch.long, device=local.device)
-        if len(idx):
-            frame[idx] = parts[r][: counts[r]]
-    return frame
+    plan = plan_for(w, row_block, world, local.device)
+    assert local.shape[0] == plan.counts[rank], (tuple(local.shape), plan.counts, rank)
+    h, c = local.shape[1], local.shape[2]
+    send, gathered = plan.buffers(h, c, local.dtype, local.device)
+    if local.shape[0] == plan.mx and local.is_contiguous():
+        send = local                                   # the common case: no staging copy
+    else:
+        send[: local.shape[0]].copy_(local)
+    dist.all_gather_into_tensor(gathered.view(-1), send.view(-1), group=group)
+    return gathered.index_select(0, plan.src)
 
 
 def render_frame(device_scene, cam, samples, w, h, cast=False, row_block=ROW_BLOCK, want="rgb", group=None):

@@ -41,6 +41,12 @@ class Mesh:
     def __len__(self):
         return N.lib().sq_mesh_num_tris(self._h)
 
+    def debug_show(self):
+        """(`show (head objs)`, `show mats`): the two lines `--debug` prints while loading (src/Obj.hs:55-57)."""
+        a, b = C.c_char_p(), C.c_char_p()
+        N.lib().sq_mesh_debug_show(self._h, C.byref(a), C.byref(b))
+        return (a.value or b"").decode("latin-1"), (b.value or b"").decode("latin-1")
+
     @property
     def tris(self) -> np.ndarray:
         n = len(self)

@@ -28,7 +28,7 @@ THREADS = min(os.cpu_count() or 1, 16)
 BIG = "big" in sys.argv
 
 
-def make_scene(rng, kinds=11):
+def make_scene(rng, kinds=12):
     kind = rng.integers(0, kinds)            # `kinds` < 10 replays seeds found before the later kinds were added
     scale = float(rng.choice([1e-3, 1.0, 1.0, 1.0, 50.0, 1e4]))
     if kind == 0:      # soup
@@ -92,6 +92,18 @@ def make_scene(rng, kinds=11):
         v = rng.uniform(-2, 2, (n, 1, 3)) + rng.normal(0, 0.4, (n, 3, 3))
         for _ in range(int(rng.integers(1, 6))):
             v[rng.integers(0, n), rng.integers(0, 3), rng.integers(0, 3)] = rng.choice([np.nan, np.inf, -np.inf])
+    elif kind == 11:   # closed room + clutter with LARGE FINITE material values (see below): radiance overflows to inf / NaN
+        r = 2.5
+        q = []
+        for ax in range(3):
+            for sgn in (-r, r):
+                a, b = [i for i in range(3) if i != ax]
+                p = np.zeros((4, 3)); p[:, ax] = sgn
+                p[:, a] = [-r, r, r, -r]; p[:, b] = [-r, -r, r, r]
+                q += [p[[0, 1, 2]], p[[0, 2, 3]]]
+        n = int(rng.integers(4, 120))
+        v = np.concatenate([np.array(q), rng.uniform(-1.8, 1.8, (n, 1, 3)) + rng.normal(0, 0.5, (n, 3, 3))])
+        scale = 1.0
     elif kind == 10:   # many identical triangles: terminal leaves of 32..200 (beyond what a packed leaf reference holds)
         base = rng.uniform(-1.5, 1.5, (int(rng.integers(1, 5)), 3, 3))
         v = np.concatenate([np.repeat(base[i:i + 1], int(rng.integers(20, 200)), 0) for i in range(len(base))] +
@@ -124,6 +136,20 @@ def make_scene(rng, kinds=11):
         mats["surf"][0, 0] = -0.5                    # negative component: the exact `== 0` shortcuts are off
     if rng.random() < 0.05:
         mats["emit"][0, 1] = np.inf                  # non-finite material: the emitter cull is off
+    if kind == 11:
+        # Every component is finite and <= 3e38, but the products are not: `emissive *^ emitColor` (src/Lib.hs:136) and
+        # `surfColor * L` overflow, and an absorbing surface (surfColor 0) in front of such radiance gives 0 * inf = NaN
+        # (src/Lib.hs:135), which the `surfColor == 0` shortcut must not replace by +0.
+        nm = int(rng.integers(2, 6))
+        mats = np.zeros(nm, sqt._native.MAT_DTYPE)
+        big = lambda size: (10.0 ** rng.uniform(18, 38.47, size)).astype(np.float32)
+        mats["reflective"] = rng.choice([0.0, 0.0, 0.3, 1.0], nm)
+        mats["surf"] = np.where(rng.random((nm, 3)) < 0.5, big((nm, 3)), rng.uniform(0, 1, (nm, 3)))
+        mats["emissive"] = rng.choice([0.0, 1.0, 1e10, 1e20, 1e30, 3e38], nm)
+        mats["emit"] = np.where(rng.random((nm, 3)) < 0.5, big((nm, 3)), rng.uniform(0, 1, (nm, 3)))
+        mats["surf"][0] = 0.0                        # the absorbing surface ...
+        mats["emissive"][0] = float(rng.choice([0.0, 5.0]))
+        mats["emissive"][nm - 1] = float(rng.choice([1e20, 1e30, 3e38, 7.0]))   # ... and the (mostly overflowing) emitter
     mat = rng.integers(0, nm, len(v))
     if rng.random() < 0.15 and len(v) > 70:          # around the 64-emitter limit of the last-bounce emitter test
         mat[:] = rng.integers(0, max(nm - 1, 1), len(v))
@@ -174,7 +200,7 @@ def canon(a):
     return u
 
 
-def run_case(seed, kinds=11):
+def run_case(seed, kinds=12):
     rng = np.random.default_rng(seed)
     v, mats, mat, scale = make_scene(rng, kinds)
     camt = make_camera(rng, scale)
@@ -208,7 +234,12 @@ def run_case(seed, kinds=11):
     cam_p, cam_o = sqt.camera_from_text(camt), O.camera_from_text(camt)
     o, o8, _ = ob.render(cam_o, spp, w, h, cast=cast, threads=THREADS)
     ds = sqt.DeviceScene(bih, 0)
+    # trace-kernel form and its tunables: pooled or one ray per lane, scene in LDS or streamed; no setting may change a bit
+    knobs = {"pool": int(rng.integers(0, 2)), "resident": int(rng.integers(0, 2)), "refill_min": int(rng.choice([1, 8, 12, 33, 64])),
+             "flush_min": int(rng.choice([0, 1, 40, 64]))}
     try:
+        for k, val in knobs.items():
+            ds.set_option(k, val)
         for variant in (2, 1):
             ds.set_option("variant", variant)
             if BIG:
@@ -219,7 +250,7 @@ def run_case(seed, kinds=11):
             a, r = a.cpu().numpy(), r.cpu().numpy()
             if not np.array_equal(canon(a), canon(o)):
                 bad = int((canon(a) != canon(o)).any(-1).sum())
-                return f"avg differs in {bad}/{w * h} pixels (variant {variant}, cast {cast}, tris {len(v)}, spp {spp}, {w}x{h})"
+                return f"avg differs in {bad}/{w * h} pixels (variant {variant}, cast {cast}, tris {len(v)}, spp {spp}, {w}x{h}, {knobs})"
             if not np.array_equal(r, o8):
                 return f"rgb8 differs (variant {variant})"
         ds.set_option("variant", 2)

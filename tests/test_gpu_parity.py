@@ -435,3 +435,95 @@ def test_one_shot_call_spreads_over_devices(sqt, product_scene, oracle_scene, mo
     # the frame workspace a freed scene leaves behind for the next one-shot call can be handed back, and comes back
     sqt.lib().sq_release_cached_memory()
     assert np.array_equal(bits(sqt.render_f32(bih, cam, 4, (64, 64))), bits(want))
+
+
+def test_render_frame_over_rccl_equals_the_unsharded_render(sqt, product_scene, dev):
+    """dist.render_frame under the `nccl` backend (= RCCL) with one rank: shard -> render -> all_gather_into_tensor ->
+    de-interleave must give exactly the frame of the unsharded render; pool and classic trace kernels agree."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    import importlib
+    d = importlib.import_module("squigly-trace_amd.dist")
+    bih, cam, _ = product_scene
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        for w, h, n in ((64, 64, 4), (37, 29, 5)):
+            want_avg, want_rgb = dev.render_rows(cam, n, w, h)
+            got_rgb = d.render_frame(dev, cam, n, w, h, want="rgb")
+            got_avg = d.render_frame(dev, cam, n, w, h, want="avg")
+            torch.cuda.synchronize()
+            assert got_rgb.shape == (w, h, 3) and torch.equal(got_rgb, want_rgb)
+            assert torch.equal(got_avg.view(torch.int32), want_avg.view(torch.int32))
+        assert np.array_equal(got_avg.cpu().numpy().view(np.uint32).shape, (37, 29, 3))
+    finally:
+        dist.destroy_process_group()
+    assert np.array_equal(bits(d.render_frame(dev, cam, 4, 64, 64, want="avg").cpu().numpy()),
+                          bits(np.load(os.path.join(GOLDEN, "scene_64x64_4spp_avg.npy"))))      # and without a process group
+
+
+def test_bench_refuses_more_ranks_than_devices(sqt):
+    """`python bench.py --gpus N` starts its own ranks; with fewer than N devices it must fail loudly, never report n_gpus: 1."""
+    import subprocess
+    import sys
+    n = sqt.device_count() + 1
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode != 0
+    assert "device" in p.stderr and "metric" not in p.stdout
+
+
+def test_pooled_and_classic_trace_kernels_agree(sqt, product_scene, oracle_scene, dev):
+    """Option `pool` (a wave tests its open leaves as pooled (ray, triangle) pairs) and its tunables change no bit."""
+    import torch
+    bih, cam, _ = product_scene
+    ob, ocam, _ = oracle_scene
+    w, h, n = 160, 120, 24
+    o, o8, _ = ob.render(ocam, n, w, h, threads=THREADS)
+    try:
+        for opts in ({"pool": 0}, {"pool": 1, "refill_min": 1, "flush_min": 0}, {"pool": 1, "refill_min": 64, "flush_min": 64},
+                     {"pool": 1, "refill_min": 12, "flush_min": 40, "resident": 0}, {"pool": 0, "resident": 0}):
+            for k, v in opts.items():
+                dev.set_option(k, v)
+            avg, rgb = dev.render_rows(cam, n, w, h)
+            torch.cuda.synchronize()
+            assert np.array_equal(bits(avg.cpu().numpy()), bits(o)), opts
+            assert np.array_equal(rgb.cpu().numpy(), o8), opts
+    finally:
+        for k, v in {"pool": 1, "refill_min": 12, "flush_min": 40, "resident": 1}.items():
+            dev.set_option(k, v)
+
+
+def test_overflowing_emission_defeats_the_absorbing_shortcut(sqt, O):
+    """`surfColor == 0` lets the HIP path skip nested rays only while the nested radiance is finite: with an emission
+    product that overflows (31-digit literals in the .sq text; every component itself is finite) the reference computes
+    0 * inf = NaN (src/Lib.hs:135) and so must the device.  Also large-but-finite products, where the bound
+    max_surf * max_e + max_e decides."""
+    from test_oracle import overflow_room_obj
+    obj = overflow_room_obj()
+    cam_txt = b"0 0 0\n0 0 0\n"
+    for emissive, emit in ((b"1" + b"0" * 30, b"1" + b"0" * 30), (b"1" + b"0" * 20, b"1" + b"0" * 19), (b"3" + b"0" * 38, b"0.5"), (b"7", b"1")):
+        sq = (b"newmtl Black\nreflective 0 0 0 0\nemissive 0 0 0 0\n\n"
+              b"newmtl Sun\nreflective 0 0 0 0\nemissive " + emissive + b" " + emit + b" " + emit + b" " + emit + b"\n")
+        ob = O.BIH(O.tris_from_text(obj, sq))
+        bih = sqt.BIH(sqt.Mesh.from_text(obj, sq))
+        for w, h, n in ((16, 16, 8), (24, 9, 33)):
+            o, o8, _ = ob.render(O.camera_from_text(cam_txt), n, w, h, threads=THREADS)
+            g = sqt.render_f32(bih, sqt.camera_from_text(cam_txt), n, (w, h))
+            g8 = sqt.render_rgb8(bih, sqt.camera_from_text(cam_txt), n, (w, h))
+            co, cg = bits(o).copy(), bits(g).copy()
+            co[np.isnan(o)] = 0x7FC00000; cg[np.isnan(g)] = 0x7FC00000      # IEEE leaves NaN payloads open
+            assert np.array_equal(co, cg), (emissive, int((co != cg).any(-1).sum()))
+            assert np.array_equal(g8, o8)
+    # surf * L overflows one level down: a grey wall with surfColor 3e38 in front of a finite but large emitter
+    sq = (b"newmtl Black\nreflective 0 " + b"3" + b"0" * 38 + b" 0 0\nemissive 0 0 0 0\n\n"
+          b"newmtl Sun\nreflective 0 0 0 0\nemissive 5 1 1 1\n")
+    ob = O.BIH(O.tris_from_text(obj, sq)); bih = sqt.BIH(sqt.Mesh.from_text(obj, sq))
+    o, o8, _ = ob.render(O.camera_from_text(cam_txt), 16, 16, 16, threads=THREADS)
+    g = sqt.render_f32(bih, sqt.camera_from_text(cam_txt), 16, (16, 16))
+    co, cg = bits(o).copy(), bits(g).copy()
+    co[np.isnan(o)] = 0x7FC00000; cg[np.isnan(g)] = 0x7FC00000
+    assert np.array_equal(co, cg)

@@ -224,3 +224,149 @@ def test_bih_build_matches_oracle_on_fuzz_scenes(sqt, O):
         fl = ob.flatten()
         assert np.array_equal(u(bih.tris["v0"]), u(fl["a"])) and np.array_equal(u(bih.tris["v1"]), u(fl["b"])) and np.array_equal(u(bih.tris["v2"]), u(fl["c"])), seed
         assert np.array_equal(u(bih.bounds), u(np.array(ob.bounds(), np.float32).ravel())), seed
+
+
+def test_debug_show_prints_haskell_show_text(sqt):
+    """--debug prints `head objs` and `mats` with Haskell's derived Show (src/Obj.hs:55-57, 88-94; src/Color.hs:78-83;
+    src/V3.hs:5).  `show :: Float`: shortest identifying digits, positional for 0.1 <= x < 10^7, else d.ddde<n>."""
+    obj = b"mtllib s.sq\no A\nv 1 2 3\nv 0.05 -0 12345678\nv 100 0.1 9999999\nusemtl M\"x\nf 1 2 3\no B\nv 0 0 0\nusemtl M\"x\nf 1 2 4\n"
+    sq = b"newmtl M\"x\nreflective 0.2 1 2 3\nemissive 100 0.608420 0.050408 0\n"
+    first, mats = sqt.Mesh.from_text(obj, sq).debug_show()
+    assert first == ('Object {verts = [V3 {_x = 1.0, _y = 3.0, _z = 2.0},V3 {_x = 5.0e-2, _y = 1.2345678e7, _z = -0.0},'
+                     'V3 {_x = 100.0, _y = 9999999.0, _z = 0.1}], mtl = "M\\"x", faces = [Face {_i1 = 1, _i2 = 2, _i3 = 3}]}')
+    assert mats == ('[("M\\"x",Mat {reflective = 0.2, surfColor = V3 {_x = 1.0, _y = 2.0, _z = 3.0}, emissive = 100.0, '
+                    'emitColor = V3 {_x = 0.60842, _y = 5.0408e-2, _z = 0.0}})]')
+    first, mats = sqt.Mesh.from_obj(os.path.join(DATA, "scene.obj"), DATA).debug_show()
+    assert first.startswith("Object {verts = [V3 {_x = 2.0, _y = -2.0, _z = -2.0},V3 {_x = 2.0, _y = 2.0, _z = -2.0},V3 {_x = 2.000001, _y = -1.999999, _z = 2.0}")
+    assert first.count("V3 {") == 25 and first.count("Face {") == 32 and 'mtl = "Material.001"' in first
+    assert mats.startswith('[("Material.004",Mat {reflective = 0.0, surfColor = V3 {_x = 5.0408e-2, _y = 5.0408e-2, _z = 5.0408e-2}, emissive = 0.0,')
+    assert '("Material.002",Mat {reflective = 0.0, surfColor = V3 {_x = 0.0, _y = 0.0, _z = 0.0}, emissive = 100.0, emitColor = V3 {_x = 1.0, _y = 1.0, _z = 1.0}})' in mats
+    assert '("Material.005",Mat {reflective = 1.0, surfColor = V3 {_x = 0.8, _y = 0.8, _z = 0.8}' in mats
+    tris = np.zeros(1, sqt._native.TRI_DTYPE); m = np.zeros(1, sqt._native.MAT_DTYPE)
+    assert sqt.Mesh.from_arrays(tris, m).debug_show() == ("", "")
+
+
+# ---- independent checks of the host loader and BIH build: nothing below goes through oracle/sq_oracle.c ----
+def _numpy_bih_check(bih_nodes, leaf_tris, mesh_tris):
+    """Re-derive makeBIH (src/BIH.hs:62-99) in numpy float32 from the INPUT triangles and walk the product's
+    pre-order node array beside it: axis (longestAxis, ties -> later axis), split plane (sequential fp32 mean of the
+    centroids, strict <), stable partition, lmax / rmin (+-0.001 on the child's vertex extreme), leaf limit 15,
+    terminal branches with an empty side, leaf order.  Returns the number of branches checked."""
+    f32 = np.float32
+    verts_of = lambda t: np.stack([t["v0"], t["v1"], t["v2"]], 1).astype(f32)          # [n, 3 verts, 3 coords]
+    pos = [0]          # next pre-order node
+    out_first = [0]    # next leaf-order triangle
+    checked = [0]
+
+    def leaf(expected):
+        nd = bih_nodes[pos[0]]; pos[0] += 1
+        assert int(nd["kind"]) & 3 == 3 and int(nd["kind"]) >> 2 == len(expected) and (len(expected) == 0 or int(nd["link"]) == out_first[0])
+        got = leaf_tris[out_first[0]: out_first[0] + len(expected)]
+        for k in ("v0", "v1", "v2", "mat"):
+            assert np.array_equal(got[k], expected[k])
+        out_first[0] += len(expected)
+
+    def walk(tris):
+        if len(tris) < 15:
+            return leaf(tris)
+        v = verts_of(tris)
+        lo, hi = v.reshape(-1, 3).min(0), v.reshape(-1, 3).max(0)                      # boundingBox of THIS node's triangles
+        dims = (hi - lo).astype(f32)
+        ax = max(range(3), key=lambda a: (dims[a], a))                                  # maximumBy keeps the last maximum
+        cen = (((f32(0) + v[:, 0]) + v[:, 1]) + v[:, 2]) / f32(3)                       # averagePoints (vertices tri)
+        plane = (np.cumsum(cen, axis=0, dtype=f32)[-1] / f32(len(tris)))[ax]            # left-to-right fp32 sum, then / n
+        under = cen[:, ax] < plane
+        left, right = tris[under], tris[~under]
+        lmax = f32(0.001) + (verts_of(left)[:, :, ax].max() if len(left) else lo[ax])
+        rmin = f32(-0.001) + (verts_of(right)[:, :, ax].min() if len(right) else hi[ax])
+        nd = bih_nodes[pos[0]]; me = pos[0]; pos[0] += 1
+        assert int(nd["kind"]) == ax, (me, int(nd["kind"]), ax)
+        assert nd["lmax"].view(np.uint32) == lmax.view(np.uint32) and nd["rmin"].view(np.uint32) == rmin.view(np.uint32), (me, nd, lmax, rmin)
+        checked[0] += 1
+        if len(left) == 0 or len(right) == 0:                                           # terminal branch: both children are leaves
+            leaf(left)
+            assert int(nd["link"]) == pos[0]
+            leaf(right)
+            return
+        walk(left)
+        assert int(nd["link"]) == pos[0], "right child index"
+        walk(right)
+
+    import sys
+    sys.setrecursionlimit(10000)
+    walk(mesh_tris)
+    assert pos[0] == len(bih_nodes) and out_first[0] == len(leaf_tris) == len(mesh_tris)
+    return checked[0]
+
+
+def test_bih_build_against_a_numpy_rederivation(sqt, product_scene):
+    bih, _, mesh = product_scene
+    assert _numpy_bih_check(bih.nodes, bih.tris, mesh.tris) == 639                      # scene.obj: 639 branches (SURVEY App. C)
+    # every triangle is in exactly one leaf: leaf order is a permutation of the input
+    key = lambda t: sorted(map(bytes, np.ascontiguousarray(t[["v0", "v1", "v2", "mat"]])))
+    assert key(bih.tris) == key(mesh.tris)
+    rng = np.random.default_rng(11)
+    for n, spread in ((400, 0.3), (60, 1.5), (15, 0.1), (14, 1.0)):
+        tris = np.zeros(n, sqt._native.TRI_DTYPE)
+        c = rng.uniform(-2, 2, (n, 1, 3))
+        v = (c + rng.normal(0, spread, (n, 3, 3))).astype(np.float32)
+        tris["v0"], tris["v1"], tris["v2"] = v[:, 0], v[:, 1], v[:, 2]
+        m = sqt.Mesh.from_arrays(tris, np.zeros(1, sqt._native.MAT_DTYPE))
+        b = sqt.BIH(m)
+        _numpy_bih_check(b.nodes, b.tris, m.tris)
+    # 40 identical triangles: the centroid mean equals every centroid, nothing is `<` it -> empty left side, terminal branch
+    tris = np.zeros(40, sqt._native.TRI_DTYPE)
+    tris["v0"], tris["v1"], tris["v2"] = [0, 0, 0], [1, 0, 0], [0, 1, 0.5]
+    m = sqt.Mesh.from_arrays(tris, np.zeros(1, sqt._native.MAT_DTYPE))
+    b = sqt.BIH(m)
+    assert _numpy_bih_check(b.nodes, b.tris, m.tris) == 1 and b.longest_leaf == 40
+
+
+def _regex_obj_loader(obj_text, sq_text):
+    """The .obj / .sq dialect of src/Obj.hs:96-161 read with regular expressions (well-formed files only): objects of
+    `v` lines, `usemtl`, optional `s on|off`, `f` lines with 1-based GLOBAL indices; swapYZ; every (object, material)
+    pair with equal names, objects outermost (makeScene, src/Obj.hs:73-77)."""
+    import re
+    num = r"-?\d+(?:\.\d+)?"
+    mats = [(m.group(1), [float(x) for x in m.groups()[1:]]) for m in re.finditer(
+        rf"newmtl (\S+)\s+reflective ({num})\s+({num})\s+({num})\s+({num})\s+emissive ({num})\s+({num})\s+({num})\s+({num})", sq_text)]
+    verts, objects = [], []
+    for blk in re.split(r"(?m)^o ", obj_text)[1:]:
+        for m in re.finditer(rf"(?m)^v\s+({num})\s+({num})\s+({num})", blk):
+            x, y, z = (np.float32(float(g)) for g in m.groups())
+            verts.append((x, z, y))                                                   # swapYZ, src/Obj.hs:112-113
+        mtl = re.search(r"(?m)^usemtl (\S+)", blk).group(1)
+        faces = [tuple(int(g) for g in m.groups()) for m in re.finditer(r"(?m)^f\s+(\d+)\s+(\d+)\s+(\d+)", blk)]
+        objects.append((mtl, faces))
+    verts = np.array(verts, np.float32)
+    out = []
+    for mtl, faces in objects:
+        for mi, (name, _) in enumerate(mats):
+            if name == mtl:
+                out += [(verts[a - 1], verts[b - 1], verts[c - 1], mi) for a, b, c in faces]
+    return out, mats
+
+
+def test_loader_against_a_regex_parser(sqt):
+    texts = [(open(os.path.join(DATA, "scene.obj"), "rb").read(), open(os.path.join(DATA, "scene.sq"), "rb").read())]
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_scenes
+    o, s, _ = gen_scenes.blob_scene(2)
+    texts.append((o, s))
+    # an object whose material is defined twice is emitted twice; an object without a material is dropped (src/Obj.hs:75)
+    texts.append((b"mtllib m.sq\no A\nv 0 0 0\nv 1 0 0\nv 0 1 0\nusemtl Twice\nf 1 2 3\no B\nv 0 0 1\nusemtl Missing\ns on\nf 1 2 4\no C\nv 2 2 2\nusemtl One\ns off\nf 5 4 1\nf 1 2 3\n",
+                  b"newmtl Twice\nreflective 0 1 1 1\nemissive 0 0 0 0\n\nnewmtl One\nreflective 1 0.5 0.25 0.125\nemissive 3 1 0 1\n\nnewmtl Twice\nreflective 0.5 0 0 0\nemissive 0 0 0 0\n"))
+    for obj, sq in texts:
+        want, mats = _regex_obj_loader(obj.decode("latin-1"), sq.decode("latin-1"))
+        mesh = sqt.Mesh.from_text(obj, sq)
+        got = mesh.tris
+        assert len(got) == len(want)
+        w0 = np.array([w[0] for w in want], np.float32); w1 = np.array([w[1] for w in want], np.float32); w2 = np.array([w[2] for w in want], np.float32)
+        assert np.array_equal(got["v0"].view(np.uint32), w0.view(np.uint32)) and np.array_equal(got["v1"].view(np.uint32), w1.view(np.uint32))
+        assert np.array_equal(got["v2"].view(np.uint32), w2.view(np.uint32)) and np.array_equal(got["mat"], [w[3] for w in want])
+        gm = mesh.materials
+        assert len(gm) == len(mats)
+        for g, (_, vals) in zip(gm, mats):
+            flat = [g["reflective"], *g["surf"], g["emissive"], *g["emit"]]
+            assert np.array_equal(np.array(flat, np.float32).view(np.uint32), np.array(vals, np.float32).view(np.uint32))

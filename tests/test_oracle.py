@@ -258,3 +258,103 @@ def test_small_and_degenerate_trees(O):
     # empty scene
     b0 = O.BIH(O.tris_from_text(b"mtllib s.sq\n", sq))
     assert b0.n_tris == 0 and b0.intersect((0, 0, -3), (0, 0, 1)).hit == 0
+
+
+def test_atan_and_tonemap_accept_non_finite_input(O):
+    """Regression for the checker's own crash in round 1 (gpurun_out/fuzz3.log): the table-driven atan
+    indexed TAB[(int)NaN] (INT_MIN on x86) for a NaN radiance, a host out-of-bounds read.  Every entry point that can
+    see a non-finite pixel must return the Haskell value: atan NaN = NaN, atan +-inf = +-pi/2, and
+    `floor :: Float -> Word8` of NaN / inf = 0 (src/Lib.hs:93-104)."""
+    import ctypes as C
+    import math
+    L = O.lib()
+    L.sqo_atan_d.restype = C.c_double
+    L.sqo_atan_d.argtypes = [C.c_double]
+    L.sqo_atanf.restype = C.c_float
+    L.sqo_atanf.argtypes = [C.c_float, C.c_int]
+    for trig in (O.TRIG_CRD, O.TRIG_LIBM):
+        assert math.isnan(L.sqo_atanf(float("nan"), trig))
+        assert L.sqo_atanf(float("inf"), trig) == np.float32(math.pi / 2)
+        assert L.sqo_atanf(float("-inf"), trig) == -np.float32(math.pi / 2)
+        assert L.sqo_atanf(3.0e38, trig) == np.float32(math.pi / 2)
+    assert math.isnan(L.sqo_atan_d(float("nan")))
+    assert L.sqo_atan_d(float("inf")) == math.pi / 2 and L.sqo_atan_d(float("-inf")) == -math.pi / 2
+    nan, inf = float("nan"), float("inf")
+    for c in ((nan, nan, nan), (nan, 1.0, 0.5), (1.0, nan, 0.5), (inf, inf, inf), (inf, 1.0, 0.0), (-inf, 2.0, 1.0), (0.0, 0.0, 0.0)):
+        for trig in (O.TRIG_CRD, O.TRIG_LIBM):
+            out = O.tonemap(c, trig)                           # must not crash; NaN / inf channels floor to 0
+            assert len(out) == 3
+    assert tuple(O.tonemap((nan, nan, nan))) == (0, 0, 0)
+    assert tuple(O.tonemap((0.0, 0.0, 0.0))) == (0, 0, 0)      # 0/0 = NaN scale: black (SURVEY A.12)
+    assert tuple(O.tonemap((inf, 1.0, 0.0))) == (0, 0, 0)      # intensity 1 / inf = 0 scale, 0 * inf = NaN -> 0
+
+
+def overflow_room_obj():
+    """A closed cube room of absorbing walls (material Black) with a lamp quad (material Sun) inside, as .obj text."""
+    r = 3
+    corners = [(x, y, z) for x in (-r, r) for y in (-r, r) for z in (-r, r)]
+    quads = [(0, 1, 3, 2), (4, 6, 7, 5), (0, 4, 5, 1), (2, 3, 7, 6), (0, 2, 6, 4), (1, 5, 7, 3)]
+    out = ["mtllib scene.sq", "o Room"] + ["v %d %d %d" % c for c in corners] + ["usemtl Black", "s off"]
+    for a, b, c, d in quads:
+        out += ["f %d %d %d" % (a + 1, b + 1, c + 1), "f %d %d %d" % (a + 1, c + 1, d + 1)]
+    out += ["o Lamp", "v -2 2.5 -2", "v 2 2.5 -2", "v 2 2.5 2", "v -2 2.5 2", "usemtl Sun", "s off", "f 9 10 11", "f 9 11 12"]
+    return ("\n".join(out) + "\n").encode()
+
+
+def test_absorbing_surface_in_front_of_overflowing_radiance_is_nan(O):
+    """src/Lib.hs:135: `surfColor * raytrace ...` with surfColor = 0 is 0 * L.  While L is finite that is +0 (the
+    shortcut the HIP path takes); when the emission `emissive *^ emitColor` overflows, L = inf and 0 * inf = NaN.
+    The .sq grammar reaches that with long digit strings (no exponent syntax, src/Obj.hs:115-121)."""
+    big = b"1" + b"0" * 30                                      # 1e30, 31 digits
+    sq = (b"newmtl Black\nreflective 0 0 0 0\nemissive 0 0 0 0\n\n"
+          b"newmtl Sun\nreflective 0 0 0 0\nemissive " + big + b" " + big + b" " + big + b" " + big + b"\n")
+    obj = overflow_room_obj()
+    tris = O.tris_from_text(obj, sq)
+    with np.errstate(over="ignore"):
+        assert np.isinf(np.float32(tris["emissive"][-1]) * np.float32(tris["emit"][-1][0]))
+    ob = O.BIH(tris)
+    cam = O.camera_from_text(b"0 0 0\n0 0 0\n")               # inside the closed black room
+    avg, rgb, _ = ob.render(cam, 8, 16, 16, threads=2)
+    assert np.isnan(avg).any(), "some scatter ray off the absorbing wall must reach the overflowing lamp"
+    assert (rgb[np.isnan(avg).any(-1)] == 0).all()
+
+
+def test_ghc_golden_pins_the_oracle(O, oracle_scene):
+    """The slot that turns "parity unpinned" into "pinned": consumes the files integration/DumpGolden.hs writes when
+    it is run against a GHC build of the reference (tests/golden/ghc_tfgen_words.bin, ghc_avg_64x64_4spp.bin) and,
+    optionally, the PNG of the reference's own CLI (`-d 64,64 -s 4 -p ghc_64x64_4spp.png`).  Skipped until they exist:
+    nobody can produce them in this repository's environments (no GHC)."""
+    words_path = os.path.join(GOLDEN, "ghc_tfgen_words.bin")
+    avg_path = os.path.join(GOLDEN, "ghc_avg_64x64_4spp.bin")
+    png_path = os.path.join(GOLDEN, "ghc_64x64_4spp.png")
+    if not (os.path.exists(words_path) or os.path.exists(avg_path) or os.path.exists(png_path)):
+        pytest.skip("no tests/golden/ghc_* files: run integration/DumpGolden.hs against a GHC build of the reference")
+    ob, cam, _ = oracle_scene
+    variant = 0
+    if os.path.exists(words_path):
+        want = np.fromfile(words_path, "<u4").reshape(4, 8)
+        seeds = [0, 1, 2, 2 ** 32 + 5]
+        matching = [v for v in range(4) if all(O.tfgen_words(s, v) == [int(x) for x in want[i]] for i, s in enumerate(seeds))]
+        assert matching, ("no TFGen layout candidate of the oracle (SURVEY App. B) reproduces tf-random's words; first seed: "
+                          f"GHC {[hex(int(x)) for x in want[0]]} vs variant 0 {[hex(x) for x in O.tfgen_words(0, 0)]}")
+        variant = matching[0]
+        assert variant == 0, f"tf-random's word layout is oracle rng_variant {variant}, not the default 0: switch the default (and sq_math.h tfgen3)"
+    cam_by_trig = {t: O.load_camera(os.path.join(DATA, "camera"), t) for t in (O.TRIG_CRD, O.TRIG_LIBM)}
+    if os.path.exists(avg_path):
+        want = np.fromfile(avg_path, "<f4").reshape(64, 64, 3)
+        stats = {}
+        for name, trig in (("crd", O.TRIG_CRD), ("libm", O.TRIG_LIBM)):
+            got, _, _ = ob.render(cam_by_trig[trig], 4, 64, 64, threads=4, trig=trig, rng_variant=variant, want_rgb=False)
+            close = np.abs(got - want).max(-1) <= 1e-4
+            stats[name] = (float(close.mean()), float((got.view(np.uint32) == want.view(np.uint32)).all(-1).mean()))
+        print("GHC avg vs oracle: fraction of pixels within 1e-4 / bit-identical:", stats)
+        # host-libm mode should agree almost everywhere (libm versions differ in the last ulp of a few calls);
+        # the crd mode the GPU uses is expected to move < 2 % of the pixels by more than 1e-4 (DESIGN.md §2)
+        assert stats["libm"][0] >= 0.98, stats
+        assert stats["crd"][0] >= 0.97, stats
+    if os.path.exists(png_path):
+        from PIL import Image
+        want8 = np.asarray(Image.open(png_path).convert("RGB"))
+        _, got8, _ = ob.render(cam_by_trig[O.TRIG_CRD], 4, 64, 64, threads=4, rng_variant=variant)
+        assert want8.shape == got8.shape
+        assert (np.abs(want8.astype(int) - got8.astype(int)).max(-1) <= 1).mean() >= 0.97
