@@ -95,7 +95,7 @@ void sq_kernel_timing_reset(sq_device_scene* s);
 int  sq_get_stats(sq_device_scene* s, uint64_t* out, int32_t n, int32_t reset);
 /* Tunables; every setting produces identical bits.  Keys:
  *   "variant"            1 = one-lane-per-pixel kernel, 2 = wavefront pipeline (default)
- *   "slots"              sample slots of the frame workspace (default 512 Mi at 60 B each = 32 GB of the
+ *   "slots"              sample slots of the frame workspace (default 512 Mi at 61 B each = 33 GB of the
  *                        288 GB; a frame with fewer samples allocates only what it needs)
  *   "resident"           1 = keep the whole scene in LDS when it fits (default), 0 = always stream
  *   "lds_node_kb"        streaming form: KB of LDS for the top of the tree (default 32)

@@ -148,7 +148,9 @@ struct Work {                 // device workspace of one frame (HBM)
     float*   px_mt;           // hit of the pixel's MIRROR bounce ray (reflectRay has no random input, so every
     int32_t* px_mtri;         //   sample of the pixel that mirrors at depth 0 shoots this same ray): t, triangle (-1 = miss)
     // per sample slot sid = k_local * A + a : the ray queue is dense in sid, dead entries are flagged
-    float4*  org;             // ray origin.xyz ; w = kLive / kDead
+    uint8_t* state;           // one byte per slot: kDone / kRay1 / kMirror / kRay2.  The trace kernel's refill scan, shade1 and
+                              //   shade2 look at this byte first and touch a slot's 60 other bytes only if they need them
+    float4*  org;             // ray origin.xyz (w unused)
     float4*  dir;             // ray direction.xyz ; w = triangle hit by ray 1 (second bounce level)
     int2*    hit;             // (t bits, tri) of the ray currently in the slot
     uint2*   rng12;           // (n1, n2) of the sample's generator
@@ -157,7 +159,9 @@ struct Work {                 // device workspace of one frame (HBM)
     unsigned long long* stats;  // cumulative trace-kernel statistics (TraceArgs::stats)
     int64_t  slot_capacity;
 };
-constexpr float kLive = 1.0f, kDead = -1.0f, kMirror = -2.0f;   // kMirror: finished tracing, result is the pixel's mirror hit
+// Slot states.  kRay1 / kRay2: the slot holds a bounce ray of depth 1 / 2 for the trace launch of that level;
+// kMirror: the sample mirrors at depth 0 and shares the pixel's mirror ray (traced once per pixel); kDone: its radiance is in `rad`.
+constexpr uint8_t kDone = 0, kRay1 = 1, kMirror = 2, kRay2 = 3;
 
 // Appends `want` lanes of this wave to a list with one atomic: wave ballot + prefix rank.
 __device__ __forceinline__ int wave_append(int32_t* counter, bool want) {
@@ -219,7 +223,7 @@ __global__ void __launch_bounds__(kBlock) sq_gen_bounce1(const SceneView S, cons
         const Pixel0 P = load_pixel0(S, F, W, a);
         if (absorbs(S, P.s0)) {
             store_rad(W, sid, P.s0.surf * sq::mk(0, 0, 0) + P.s0.emit);
-            W.org[sid] = make_float4(0, 0, 0, kDead);
+            W.state[sid] = kDone;
             continue;
         }
         const long long rix = (long long)F.samples * ((long long)P.x + (long long)P.y * (long long)F.w);   // src/Lib.hs:85
@@ -227,11 +231,12 @@ __global__ void __launch_bounds__(kBlock) sq_gen_bounce1(const SceneView S, cons
         sq::tfgen3(rix + k, n0, n1, n2);                                // mkTFGen (rix + k), src/Lib.hs:86
         W.rng12[sid] = make_uint2(n1, n2);
         if (!scatters(P.s0, n0)) {                                      // mirror: traced once per pixel (sq_mirror1_*)
-            W.org[sid] = make_float4(P.p0.x, P.p0.y, P.p0.z, kMirror);
+            W.state[sid] = kMirror;
             continue;
         }
         const f3 d1 = scatter_dir(P.d0, P.s0, n0, n1);
-        W.org[sid] = make_float4(P.p0.x, P.p0.y, P.p0.z, kLive);
+        W.state[sid] = kRay1;
+        W.org[sid] = make_float4(P.p0.x, P.p0.y, P.p0.z, 0.0f);
         W.dir[sid] = make_float4(d1.x, d1.y, d1.z, 0.0f);
     }
 }
@@ -241,16 +246,17 @@ __global__ void __launch_bounds__(kBlock) sq_mirror1_gen(const SceneView S, cons
     const int A = *W.n_active;
     for (int a = blockIdx.x * kBlock + threadIdx.x; a < A; a += gridDim.x * kBlock) {
         const Pixel0 P = load_pixel0(S, F, W, a);
-        if (absorbs(S, P.s0)) { W.org[a] = make_float4(0, 0, 0, kDead); continue; }
+        if (absorbs(S, P.s0)) { W.state[a] = kDone; continue; }
         const f3 d1 = mirror_dir(P.d0, P.s0);
-        W.org[a] = make_float4(P.p0.x, P.p0.y, P.p0.z, kLive);
+        W.state[a] = kRay1;
+        W.org[a] = make_float4(P.p0.x, P.p0.y, P.p0.z, 0.0f);
         W.dir[a] = make_float4(d1.x, d1.y, d1.z, 0.0f);
     }
 }
 __global__ void __launch_bounds__(kBlock) sq_mirror1_store(const Work W) {
     const int A = *W.n_active;
     for (int a = blockIdx.x * kBlock + threadIdx.x; a < A; a += gridDim.x * kBlock) {
-        const bool live = W.org[a].w >= 0.0f;
+        const bool live = W.state[a] == kRay1;
         const int2 hit = W.hit[a];
         W.px_mt[a] = live ? __int_as_float(hit.x) : 0.0f;
         W.px_mtri[a] = live ? hit.y : -1;
@@ -261,49 +267,58 @@ __global__ void __launch_bounds__(kBlock) sq_mirror1_store(const Work W) {
 __global__ void __launch_bounds__(kBlock) sq_shade1(const SceneView S, const Frame F, const Work W, int k_count) {
     const int A = *W.n_active;
     const unsigned total = (unsigned)A * (unsigned)k_count;
-    // The kernel waits on memory four fifths of its time, so everything a slot can need is requested up front, one
-    // level of dependent loads at a time, and the first level of the NEXT slot is requested before this one is worked on.
-    struct First { float4 org, dir; int2 hit; uint2 r; int a, tri0; };
-    auto first = [&](unsigned sid) {
-        First f;
-        f.org = W.org[sid]; f.dir = W.dir[sid]; f.hit = W.hit[sid]; f.r = W.rng12[sid];
-        f.a = (int)(sid % (unsigned)A); f.tri0 = W.px_tri0[f.a];
-        return f;
+    // Memory-bound (it waits on memory two thirds of its time): a slot's state byte decides what else is read --
+    // nothing for a finished slot, the generator words for a mirrored one (its ray and hit are the pixel's), everything
+    // for a traced one -- and the state and generator words of the NEXT slot are requested before this one is worked on.
+    // Two slots ahead: its state byte and generator words.  One slot ahead: what that state says is needed (ray and
+    // hit of a traced slot; the pixel's mirror hit of a mirrored one) and the primary triangle.  Then the slot itself.
+    struct First { uint8_t st; uint2 r; };
+    struct Second { float4 org, dir; int2 hit; int a, tri0; };
+    auto first = [&](unsigned sid) { First f; f.st = W.state[sid]; f.r = W.rng12[sid]; return f; };
+    auto second = [&](unsigned sid, uint8_t st) {
+        Second q{};
+        if (st == kDone) return q;
+        q.a = (int)(sid % (unsigned)A); q.tri0 = W.px_tri0[q.a];
+        if (st == kMirror) q.hit = make_int2(__float_as_int(W.px_mt[q.a]), W.px_mtri[q.a]);
+        else { q.org = W.org[sid]; q.dir = W.dir[sid]; q.hit = W.hit[sid]; }
+        return q;
     };
     const unsigned stride = gridDim.x * kBlock;
     unsigned sid = blockIdx.x * kBlock + threadIdx.x;
-    First nxt{};
-    if (sid < total) nxt = first(sid);
+    First f1{}, f2{}; Second q1{};
+    if (sid < total) { f1 = first(sid); q1 = second(sid, f1.st); }
+    if (sid + stride < total) f2 = first(sid + stride);
     for (; sid < total; sid += stride) {
-        const First cur = nxt;
-        if (sid + stride < total) nxt = first(sid + stride);
-        const float4 org = cur.org, dir = cur.dir;
-        int2 hit = cur.hit;
+        const First cur = f1; const Second q = q1;
+        f1 = f2;
+        if (sid + stride < total) q1 = second(sid + stride, f1.st);
+        if (sid + 2 * stride < total && sid + 2 * stride > sid) f2 = first(sid + 2 * stride);
+        if (cur.st == kDone) continue;
         const uint2 r = cur.r;
-        const int a = cur.a, tri0 = cur.tri0;
-        if (org.w == kDead) continue;
-        const bool mirrored = (org.w == kMirror);
+        const int a = q.a, tri0 = q.tri0;
         const Surface s0 = surface_of(S, tri0);                         // every finished path folds it in
-        f3 d1 = sq::mk(dir.x, dir.y, dir.z);
-        if (mirrored) {                                                 // the pixel's mirror ray and its hit
+        f3 d1, p0;
+        const int2 hit = q.hit;
+        if (cur.st == kMirror) {                                        // the pixel's mirror ray and its hit
             const Pixel0 P = load_pixel0(S, F, W, a);
-            d1 = mirror_dir(P.d0, P.s0);
-            hit = make_int2(__float_as_int(W.px_mt[a]), W.px_mtri[a]);
+            d1 = mirror_dir(P.d0, P.s0); p0 = P.p0;
+        } else {
+            d1 = sq::mk(q.dir.x, q.dir.y, q.dir.z); p0 = sq::mk(q.org.x, q.org.y, q.org.z);
         }
         const int tri1 = hit.y;
         if (tri1 < 0) {                                                 // raytrace ... 1 = black
             store_rad(W, sid, s0.surf * sq::mk(0, 0, 0) + s0.emit);
-            W.org[sid].w = kDead;
+            W.state[sid] = kDone;
             continue;
         }
         const Surface s1 = surface_of(S, tri1);
         if (absorbs(S, s1)) {
             const f3 L1 = s1.surf * sq::mk(0, 0, 0) + s1.emit;
             store_rad(W, sid, s0.surf * L1 + s0.emit);
-            W.org[sid].w = kDead;
+            W.state[sid] = kDone;
             continue;
         }
-        const f3 p1 = sq::mk(org.x, org.y, org.z) + sq::scale(__int_as_float(hit.x), d1);
+        const f3 p1 = p0 + sq::scale(__int_as_float(hit.x), d1);
         const f3 d2 = bounce_dir(d1, s1, r.x, r.y);                     // gen advanced by one: x = u = p(n1), v = p(n2)
         // Ray 2 is the last one: all it contributes is L2 = s2*0 + e2, the emission of whatever it hits
         // (src/Lib.hs:129,135-137).  Whatever the traversal returns is a triangle that mollerTrumbore accepted
@@ -321,11 +336,12 @@ __global__ void __launch_bounds__(kBlock) sq_shade1(const SceneView S, const Fra
             if (!may_reach) {
                 const f3 L1 = s1.surf * sq::mk(0, 0, 0) + s1.emit;
                 store_rad(W, sid, s0.surf * L1 + s0.emit);
-                W.org[sid].w = kDead;
+                W.state[sid] = kDone;
                 continue;
             }
         }
-        W.org[sid] = make_float4(p1.x, p1.y, p1.z, kLive);
+        W.state[sid] = kRay2;
+        W.org[sid] = make_float4(p1.x, p1.y, p1.z, 0.0f);
         W.dir[sid] = make_float4(d2.x, d2.y, d2.z, __int_as_float(tri1));
     }
 }
@@ -335,7 +351,7 @@ __global__ void __launch_bounds__(kBlock) sq_shade2(const SceneView S, const Fra
     const int A = *W.n_active;
     const unsigned total = (unsigned)A * (unsigned)k_count;
     for (unsigned sid = blockIdx.x * kBlock + threadIdx.x; sid < total; sid += gridDim.x * kBlock) {
-        if (W.org[sid].w < 0) continue;
+        if (W.state[sid] != kRay2) continue;                            // 8 % of the slots on the headline frame
         const int tri1 = __float_as_int(W.dir[sid].w), tri2 = W.hit[sid].y;
         f3 L2 = sq::mk(0, 0, 0);
         if (tri2 >= 0) { const Surface s2 = surface_of(S, tri2); L2 = s2.surf * sq::mk(0, 0, 0) + s2.emit; }
@@ -370,6 +386,7 @@ __global__ void __launch_bounds__(kBlock) sq_accumulate(const Frame F, const Wor
 // keeps its frame stack in LDS (lane-minor layout, one word per frame, at most height-1 frames).
 struct TraceArgs {
     const float4* org; const float4* dir; int2* hits;
+    const uint8_t* state; int32_t want;      // a slot is in this launch's queue iff state[slot] == want (kRay1 / kRay2)
     const int32_t* n_active; int32_t k_count; int32_t* head;
     int32_t n_lds; int32_t stack_cap; int32_t straggler_lanes;
     int32_t chunk;               // slots per reservation: a multiple of 64, at most kChunkResident / kChunkStreaming
@@ -467,7 +484,7 @@ __global__ void __launch_bounds__(BLOCK) sq_trace_rays(const SceneView S, const 
             for (int j = 0; j < kChunk / 64; ++j) {
                 if (j * 64 >= A.chunk) break;
                 const long long idx = chunk_base + j * 64 + lane;
-                const bool alive = idx < n && A.org[idx].w >= 0.0f;
+                const bool alive = idx < n && A.state[idx] == (uint8_t)A.want;
                 const unsigned long long am = __ballot(alive);
                 if (alive) live[list_len + __popcll(am & lt_mask)] = (LiveT)((j & 3) * 64 + lane);   // index within its 256-slot block
                 list_len += __popcll(am);
@@ -1029,14 +1046,14 @@ int ensure_workspace(sq_device_scene* s, int64_t pixels, int64_t slots) {
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     if (s->d_work) { cache_give(s->device, s->d_work, s->work_bytes); s->d_work = nullptr; s->work_pixels = s->work_slots = 0; }
     size_t block_bytes = 0;
-    size_t off = 0, o_cnt = 0, o_stats = 0, o_pix = 0, o_t0 = 0, o_tri0 = 0, o_sum = 0, o_mt = 0, o_mtri = 0, o_org = 0, o_dir = 0, o_hit = 0, o_rng = 0, o_rad = 0;
+    size_t off = 0, o_cnt = 0, o_stats = 0, o_pix = 0, o_t0 = 0, o_tri0 = 0, o_sum = 0, o_mt = 0, o_mtri = 0, o_state = 0, o_org = 0, o_dir = 0, o_hit = 0, o_rng = 0, o_rad = 0;
     for (;;) {
         off = 0;
         auto take = [&](size_t bytes) { size_t o = off; off += al(bytes); return o; };
         o_cnt = take(128 * sizeof(int32_t)); o_stats = take(kStatSlots * sizeof(unsigned long long));
         o_pix = take(pixels * 4); o_t0 = take(pixels * 4); o_tri0 = take(pixels * 4); o_sum = take(pixels * 12);
         o_mt = take(pixels * 4); o_mtri = take(pixels * 4);
-        o_org = take(slots * 16); o_dir = take(slots * 16); o_hit = take(slots * 8); o_rng = take(slots * 8); o_rad = take(slots * 12);
+        o_state = take(slots); o_org = take(slots * 16); o_dir = take(slots * 16); o_hit = take(slots * 8); o_rng = take(slots * 8); o_rad = take(slots * 12);
         block_bytes = off;
         if ((s->d_work = cache_take(s->device, off, &block_bytes)) != nullptr) break;
         if (hipMalloc(&s->d_work, off) == hipSuccess) break;
@@ -1053,7 +1070,7 @@ int ensure_workspace(sq_device_scene* s, int64_t pixels, int64_t slots) {
     if (hipMemset(W.stats, 0, kStatSlots * sizeof(unsigned long long)) != hipSuccess) return sq_set_error("hipMemset failed");
     W.px_pixel = (int32_t*)(base + o_pix); W.px_t0 = (float*)(base + o_t0); W.px_tri0 = (int32_t*)(base + o_tri0); W.px_sum = (float*)(base + o_sum);
     W.px_mt = (float*)(base + o_mt); W.px_mtri = (int32_t*)(base + o_mtri);
-    W.org = (float4*)(base + o_org); W.dir = (float4*)(base + o_dir); W.hit = (int2*)(base + o_hit);
+    W.state = (uint8_t*)(base + o_state); W.org = (float4*)(base + o_org); W.dir = (float4*)(base + o_dir); W.hit = (int2*)(base + o_hit);
     W.rng12 = (uint2*)(base + o_rng); W.rad = (float*)(base + o_rad);
     W.slot_capacity = slots;
     s->work_bytes = block_bytes; s->work_pixels = pixels; s->work_slots = slots;
@@ -1102,7 +1119,7 @@ int launch_frame(sq_device_scene* s, const Frame& F, hipStream_t stream) {
     Work Wt[2] = { W, W };
     if (overlap) {
         Work& V = Wt[1];
-        V.org += track_slots; V.dir += track_slots; V.hit += track_slots; V.rng12 += track_slots; V.rad += 3 * track_slots;
+        V.state += track_slots; V.org += track_slots; V.dir += track_slots; V.hit += track_slots; V.rng12 += track_slots; V.rad += 3 * track_slots;
         V.head[0] = W.n_active + 64 + 16; V.head[1] = W.n_active + 64 + 32;
     }
     // samples per batch: as many as a track holds, split evenly (few large launches: a small trace launch
@@ -1152,7 +1169,7 @@ int launch_frame(sq_device_scene* s, const Frame& F, hipStream_t stream) {
         const int max_chunk = resident ? kChunkResident : kChunkStreaming;
         const int64_t per_wave = pixels * (int64_t)kc / std::max(1, trace_blocks * (trace_threads / 64));
         const int chunk = (int)std::min<int64_t>(max_chunk, std::max<int64_t>(64, (per_wave / 8) / 64 * 64));
-        TraceArgs A{ W.org, W.dir, W.hit, W.n_active, kc, W.head[level], n_lds, stack_cap, (int32_t)s->opt_straggler, chunk,
+        TraceArgs A{ W.org, W.dir, W.hit, W.state, level == 0 ? (int32_t)kRay1 : (int32_t)kRay2, W.n_active, kc, W.head[level], n_lds, stack_cap, (int32_t)s->opt_straggler, chunk,
                      (int32_t)s->opt_refill_min, (int32_t)s->opt_flush_min, W.stats };
         return timed([&] {
             void* kargs[] = { (void*)&S, (void*)&A };
