@@ -69,7 +69,7 @@ def launch_ranks(args):
     call (torch.cuda.device_count() only counts devices on this image) and never replaces itself."""
     import torch
     have = torch.cuda.device_count()
-    if have < args.gpus:
+    if have < args.gpus and not (args.oversubscribe and have >= 1):
         print(f"bench.py: --gpus {args.gpus} but only {have} HIP device(s) are visible; refusing to report a "
               f"{args.gpus}-GPU number from fewer devices", file=sys.stderr)
         return 2
@@ -143,6 +143,10 @@ def main():
     ap.add_argument("--no-other", action="store_true", help="skip the C3/C5 stand-in configurations (N = 1 only)")
     ap.add_argument("--no-oneshot", action="store_true", help="skip the one-shot call's wall time (profiling runs: keeps the launch count per step)")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and gather even with one rank (self-test)")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="nccl = RCCL over xGMI (the product path); gloo only for plumbing tests")
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="TEST ONLY: let ranks share devices (rank r uses device r %% visible) so that the N-rank path can be "
+                         "exercised on a one-GPU box with --backend gloo; the line it prints is marked and is not a measurement")
     args = ap.parse_args()
     if args.gpus < 1:
         ap.error("--gpus must be positive")
@@ -165,6 +169,8 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.oversubscribe and torch.cuda.device_count() >= 1:
+        local_rank %= torch.cuda.device_count()
     if torch.cuda.device_count() <= local_rank:
         print(f"bench.py: rank {rank} has no device {local_rank} ({torch.cuda.device_count()} visible)", file=sys.stderr)
         sys.exit(2)
@@ -175,7 +181,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
     world = dist.get_world_size() if use_dist else 1          # the ranks RCCL actually connected
 
     data = os.path.join(ROOT, "data")
@@ -219,6 +228,8 @@ def main():
             "metric": "Msamples/s (whole node) at 1080p/256spp on data/scene.obj",
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": args.scaling,
+            **({"not_a_measurement": "ranks share devices (--oversubscribe) or gather over gloo: plumbing test only"}
+               if (args.oversubscribe or args.backend != "nccl") else {}),
             "vs_baseline": None, "dtype": "f32", "data": "data/scene.obj + data/scene.sq + data/camera (the reference's sample scene)",
             "parity": "bit-identical to this repository's C restatement of the Haskell (oracle/); unpinned against a GHC build of the reference",
             "config": {"workload": f"data/scene.obj {w}x{h} @ {spp} spp (BASELINE configs[{1 if args.config == 'c2' else 3}]"

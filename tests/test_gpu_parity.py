@@ -527,3 +527,27 @@ def test_overflowing_emission_defeats_the_absorbing_shortcut(sqt, O):
     co, cg = bits(o).copy(), bits(g).copy()
     co[np.isnan(o)] = 0x7FC00000; cg[np.isnan(g)] = 0x7FC00000
     assert np.array_equal(co, cg)
+
+
+def test_bench_launches_its_own_ranks(sqt):
+    """`python bench.py --gpus 2` with no torchrun around it: the parent starts two rank processes, they shard the frame,
+    gather it and rank 0's JSON line comes back through the parent.  On this one-GPU box the two ranks share the device
+    and gather over gloo (test-only flags; RCCL refuses two ranks on one GPU); the line is marked as not a measurement."""
+    import json
+    import subprocess
+    import sys
+    common = ["--steps", "1", "--warmup", "1", "--no-cpu", "--no-other", "--width", "96", "--height", "64", "--spp", "8"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common, env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    j1 = json.loads(one.stdout.strip().splitlines()[-1])
+    two = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--oversubscribe"] + common, env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert two.returncode == 0, two.stderr[-3000:]
+    lines = [ln for ln in two.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, two.stdout                                  # exactly one line, rank 0's
+    j2 = json.loads(lines[0])
+    assert j1["n_gpus"] == 1 and j2["n_gpus"] == 2 and j2["scaling"] == "strong" and "not_a_measurement" in j2
+    assert j2["config"]["samples_per_step"] == j1["config"]["samples_per_step"] == 96 * 64 * 8      # the SAME frame, shared
+    assert j2["config"]["nonblack_pixels"] == j1["config"]["nonblack_pixels"] > 0                   # and the same image
