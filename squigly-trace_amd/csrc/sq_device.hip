@@ -242,22 +242,25 @@ __global__ void __launch_bounds__(kBlock) sq_gen_bounce1(const SceneView S, cons
 }
 
 // The depth-0 mirror ray of every active pixel, once per frame (slot a = active pixel a).
-__global__ void __launch_bounds__(kBlock) sq_mirror1_gen(const SceneView S, const Frame F, const Work W) {
+// `base`: first of the *n_active slots the mirror rays use (0 when they have a launch of their own, the spare region
+// behind the sample slots when they ride at the head of the first bounce launch).
+__global__ void __launch_bounds__(kBlock) sq_mirror1_gen(const SceneView S, const Frame F, const Work W, long long base) {
     const int A = *W.n_active;
     for (int a = blockIdx.x * kBlock + threadIdx.x; a < A; a += gridDim.x * kBlock) {
         const Pixel0 P = load_pixel0(S, F, W, a);
-        if (absorbs(S, P.s0)) { W.state[a] = kDone; continue; }
+        const long long sl = base + a;
+        if (absorbs(S, P.s0)) { W.state[sl] = kDone; continue; }
         const f3 d1 = mirror_dir(P.d0, P.s0);
-        W.state[a] = kRay1;
-        W.org[a] = make_float4(P.p0.x, P.p0.y, P.p0.z, 0.0f);
-        W.dir[a] = make_float4(d1.x, d1.y, d1.z, 0.0f);
+        W.state[sl] = kRay1;
+        W.org[sl] = make_float4(P.p0.x, P.p0.y, P.p0.z, 0.0f);
+        W.dir[sl] = make_float4(d1.x, d1.y, d1.z, 0.0f);
     }
 }
-__global__ void __launch_bounds__(kBlock) sq_mirror1_store(const Work W) {
+__global__ void __launch_bounds__(kBlock) sq_mirror1_store(const Work W, long long base) {
     const int A = *W.n_active;
     for (int a = blockIdx.x * kBlock + threadIdx.x; a < A; a += gridDim.x * kBlock) {
-        const bool live = W.state[a] == kRay1;
-        const int2 hit = W.hit[a];
+        const bool live = W.state[base + a] == kRay1;
+        const int2 hit = W.hit[base + a];
         W.px_mt[a] = live ? __int_as_float(hit.x) : 0.0f;
         W.px_mtri[a] = live ? hit.y : -1;
     }
@@ -387,9 +390,14 @@ __global__ void __launch_bounds__(kBlock) sq_accumulate(const Frame F, const Wor
 struct TraceArgs {
     const float4* org; const float4* dir; int2* hits;
     const uint8_t* state; int32_t want;      // a slot is in this launch's queue iff state[slot] == want (kRay1 / kRay2)
+    long long front_base; int32_t front;     // front != 0: the queue starts with *n_active extra entries, the slots
+                                             //   front_base + [0, *n_active) (the per-pixel mirror rays ride at the head of the
+                                             //   first bounce launch instead of having a launch, and a ramp-down, of their own)
     const int32_t* n_active; int32_t k_count; int32_t* head;
     int32_t n_lds; int32_t stack_cap; int32_t straggler_lanes;
     int32_t chunk;               // slots per reservation: a multiple of 64, at most kChunkResident / kChunkStreaming
+    int32_t guide_shift;         // towards the end of the queue a reservation shrinks to (slots left >> guide_shift), so that the
+                                 //   launch does not end with a few waves still working through a full reservation
     int32_t refill_min;          // pooled form: idle lanes a wave collects before it fetches new rays for them
     int32_t flush_min;           // pooled form: a trailing part-filled window of the pair pool is run at once from this many pairs on
     unsigned long long* stats;   // [0] rays traced; PROFILE builds: [1] advance iterations (waves), [2] lanes unwinding,
@@ -459,10 +467,13 @@ __global__ void __launch_bounds__(BLOCK) sq_trace_rays(const SceneView S, const 
         root_ref = S.root_ref;
     }
     __syncthreads();
-    const long long n = (long long)(*A.n_active) * A.k_count;
+    const long long n_front = A.front ? (long long)(*A.n_active) : 0;
+    const long long n = (long long)(*A.n_active) * A.k_count + n_front;          // queue positions; slot_of() maps them to slots
+    auto slot_of = [&](long long q) { return q < n_front ? A.front_base + q : q - n_front; };
     const int lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     long long chunk_base = 0;               // wave-uniform
+    int my_chunk = A.chunk;                 // wave-uniform: size of this wave's next reservation
     int list_pos = 0, list_len = 0;         // wave-uniform
     bool exhausted = false;                 // wave-uniform
     long long my_ray = -1;
@@ -475,16 +486,22 @@ __global__ void __launch_bounds__(BLOCK) sq_trace_rays(const SceneView S, const 
     auto refill = [&](unsigned long long m, bool idle) {             // m = ballot(idle), wave-uniform
         while (!exhausted && list_pos == list_len) {                    // reserve and compact the next chunk
             int base = 0;
-            if (lane == 0) base = atomicAdd(A.head, A.chunk);
+            if (lane == 0) base = atomicAdd(A.head, my_chunk);
             base = __builtin_amdgcn_readfirstlane(base);
             if (base >= n) { exhausted = true; break; }
+            const int this_chunk = my_chunk;
+            {   // guided self-scheduling: the next reservation is 1/(4 x waves) of what is left, between 64 and A.chunk slots
+                const long long left = n - ((long long)base + this_chunk);
+                const long long want = A.guide_shift >= 62 ? (long long)A.chunk : ((left >> A.guide_shift) & ~63ll);
+                my_chunk = (int)(want < 64 ? 64 : (want > A.chunk ? A.chunk : want));
+            }
             chunk_base = base; list_pos = 0; list_len = 0;
             sub_end[0] = sub_end[1] = sub_end[2] = 0x7fffffff;          // blocks a short reservation does not reach
 #pragma unroll
             for (int j = 0; j < kChunk / 64; ++j) {
-                if (j * 64 >= A.chunk) break;
+                if (j * 64 >= this_chunk) break;
                 const long long idx = chunk_base + j * 64 + lane;
-                const bool alive = idx < n && A.state[idx] == (uint8_t)A.want;
+                const bool alive = idx < n && A.state[slot_of(idx)] == (uint8_t)A.want;
                 const unsigned long long am = __ballot(alive);
                 if (alive) live[list_len + __popcll(am & lt_mask)] = (LiveT)((j & 3) * 64 + lane);   // index within its 256-slot block
                 list_len += __popcll(am);
@@ -506,7 +523,7 @@ __global__ void __launch_bounds__(BLOCK) sq_trace_rays(const SceneView S, const 
             if (kChunk > 256) block += p >= sub_end[0];
             if (kChunk > 512) block += p >= sub_end[1];
             if (kChunk > 768) block += p >= sub_end[2];
-            my_ray = chunk_base + block * 256 + live[p];
+            my_ray = slot_of(chunk_base + block * 256 + live[p]);
             const float4 o = A.org[my_ray], d = A.dir[my_ray];
             trav_begin(T, S, root_ref, sq::mk(o.x, o.y, o.z), sq::mk(d.x, d.y, d.z));
         }
@@ -716,7 +733,7 @@ struct sq_device_scene {
     // second stream of the overlapped schedule (launch_frame) and its event pool
     hipStream_t aux = nullptr; std::vector<hipEvent_t> events;
     int64_t opt_overlap = 0, opt_aux_blocks_per_cu = 0;
-    int64_t opt_pool = 1, opt_refill_min = 12, opt_flush_min = 40;
+    int64_t opt_pool = 1, opt_refill_min = 12, opt_flush_min = 40, opt_guided = 1;
 };
 
 namespace {
@@ -1053,7 +1070,13 @@ int ensure_workspace(sq_device_scene* s, int64_t pixels, int64_t slots) {
         o_cnt = take(128 * sizeof(int32_t)); o_stats = take(kStatSlots * sizeof(unsigned long long));
         o_pix = take(pixels * 4); o_t0 = take(pixels * 4); o_tri0 = take(pixels * 4); o_sum = take(pixels * 12);
         o_mt = take(pixels * 4); o_mtri = take(pixels * 4);
-        o_state = take(slots); o_org = take(slots * 16); o_dir = take(slots * 16); o_hit = take(slots * 8); o_rng = take(slots * 8); o_rad = take(slots * 12);
+        // + pixels: the mirror rays' spare region behind the sample slots (state, ray and hit only)
+        o_state = take(slots + pixels); o_org = take((slots + pixels) * 16); o_dir = take((slots + pixels) * 16);
+        o_hit = take((slots + pixels) * 8); o_rng = take(slots * 8); o_rad = take(slots * 12);
+        // every array has its own, ordered place in the block: a slip here would be a GPU fault, not an error code
+        if (!(o_cnt < o_stats && o_stats < o_pix && o_pix < o_t0 && o_t0 < o_tri0 && o_tri0 < o_sum && o_sum < o_mt && o_mt < o_mtri &&
+              o_mtri < o_state && o_state < o_org && o_org < o_dir && o_dir < o_hit && o_hit < o_rng && o_rng < o_rad && o_rad < off))
+            return sq_set_error("internal error: frame workspace layout");
         block_bytes = off;
         if ((s->d_work = cache_take(s->device, off, &block_bytes)) != nullptr) break;
         if (hipMalloc(&s->d_work, off) == hipSuccess) break;
@@ -1086,20 +1109,20 @@ int launch_frame(sq_device_scene* s, const Frame& F, hipStream_t stream) {
     const long long px_blocks = (pixels + kBlock - 1) / kBlock;
     if (px_blocks > 0x7fffffffLL) return sq_set_error("image too large for one launch");
     if (px_lds > 160 * 1024) return sq_set_error("BIH height %d needs %zu B of LDS stack per workgroup (max 163840)", S.height, px_lds);
-    auto timed = [&](auto&& fn, const char* name) -> int {
+    auto timed = [&](auto&& fn, const char* name, hipStream_t on) -> int {
         hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (s->opt_timing) { SQ_HIP(hipEventCreate(&e0)); SQ_HIP(hipEventCreate(&e1)); SQ_HIP(hipEventRecord(e0, stream)); }
+        if (s->opt_timing) { SQ_HIP(hipEventCreate(&e0)); SQ_HIP(hipEventCreate(&e1)); SQ_HIP(hipEventRecord(e0, on)); }
         fn();
         SQ_HIP(hipGetLastError());
         if (s->opt_timing) {
-            SQ_HIP(hipEventRecord(e1, stream)); s->pending.emplace_back(e0, e1); s->last_kernel = name;
+            SQ_HIP(hipEventRecord(e1, on)); s->pending.emplace_back(e0, e1); s->last_kernel = name;
             if (s->pending.size() > 8192) SQ_HIP(sq_kernel_timing(s, nullptr, nullptr, nullptr) ? hipErrorUnknown : hipSuccess);   // fold, bounded memory
         }
         return 0;
     };
     if (s->opt_variant == 1 || F.cast) {
         if (px_lds > 64 * 1024) SQ_HIP(hipFuncSetAttribute((const void*)sq_render_pixels<StackT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)px_lds));
-        return timed([&] { hipLaunchKernelGGL(sq_render_pixels<StackT>, dim3((unsigned)px_blocks), dim3(kBlock), px_lds, stream, S, F); }, "sq_render_pixels");
+        return timed([&] { hipLaunchKernelGGL(sq_render_pixels<StackT>, dim3((unsigned)px_blocks), dim3(kBlock), px_lds, stream, S, F); }, "sq_render_pixels", stream);
     }
     // ---- wavefront pipeline ----
     // at least one sample of every pixel per batch, never more slots than the frame has samples
@@ -1164,25 +1187,34 @@ int launch_frame(sq_device_scene* s, const Frame& F, hipStream_t stream) {
     const size_t tr_lds = L.total;
     if (tr_lds > 64 * 1024) SQ_HIP(hipFuncSetAttribute(trace_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tr_lds));
     const int aux_blocks = s->n_cu * (int)(s->opt_aux_blocks_per_cu ? s->opt_aux_blocks_per_cu : 8);
-    auto launch_trace = [&](const Work& W, int kc, int level) -> int {
+    auto launch_trace = [&](const Work& W, int kc, int level, hipStream_t on, bool with_mirror_rays = false) -> int {
         // a launch with few slots (the per-pixel mirror rays) takes small reservations, or only a few waves get any
         const int max_chunk = resident ? kChunkResident : kChunkStreaming;
         const int64_t per_wave = pixels * (int64_t)kc / std::max(1, trace_blocks * (trace_threads / 64));
         const int chunk = (int)std::min<int64_t>(max_chunk, std::max<int64_t>(64, (per_wave / 8) / 64 * 64));
-        TraceArgs A{ W.org, W.dir, W.hit, W.state, level == 0 ? (int32_t)kRay1 : (int32_t)kRay2, W.n_active, kc, W.head[level], n_lds, stack_cap, (int32_t)s->opt_straggler, chunk,
+        int guide_shift = 2;                                            // log2(4 x waves of the launch), rounded up
+        while ((1ll << guide_shift) < 4ll * trace_blocks * (trace_threads / 64)) ++guide_shift;
+        if (!s->opt_guided) guide_shift = 62;
+        TraceArgs A{ W.org, W.dir, W.hit, W.state, level == 0 ? (int32_t)kRay1 : (int32_t)kRay2, (long long)s->work.slot_capacity, with_mirror_rays ? 1 : 0,
+                     W.n_active, kc, W.head[level], n_lds, stack_cap, (int32_t)s->opt_straggler, chunk, guide_shift,
                      (int32_t)s->opt_refill_min, (int32_t)s->opt_flush_min, W.stats };
         return timed([&] {
             void* kargs[] = { (void*)&S, (void*)&A };
-            (void)hipLaunchKernel(trace_fn, dim3(trace_blocks), dim3(trace_threads), kargs, tr_lds, stream);
-        }, "sq_trace_rays");
+            (void)hipLaunchKernel(trace_fn, dim3(trace_blocks), dim3(trace_threads), kargs, tr_lds, on);
+        }, "sq_trace_rays", on);
     };
-    // once per frame: the depth-0 mirror ray of every active pixel (reused by every sample that mirrors)
-    SQ_HIP(hipMemsetAsync(W.head[0], 0, 32 * sizeof(int32_t), stream));
-    hipLaunchKernelGGL(sq_mirror1_gen, dim3(aux_blocks), dim3(kBlock), 0, stream, S, F, W);
-    SQ_HIP(hipGetLastError());
-    if (launch_trace(W, 1, 0)) return 1;
-    hipLaunchKernelGGL(sq_mirror1_store, dim3(aux_blocks), dim3(kBlock), 0, stream, W);
-    SQ_HIP(hipGetLastError());
+    // once per frame: the depth-0 mirror ray of every active pixel (reused by every sample that mirrors).  In the plain
+    // schedule these rays ride at the head of the first batch's first bounce launch (slots behind the sample slots,
+    // dequeued first); the overlapped schedules give them a launch of their own, before the tracks split.
+    const bool mirror_rides = !overlap;
+    if (!mirror_rides) {
+        SQ_HIP(hipMemsetAsync(W.head[0], 0, 32 * sizeof(int32_t), stream));
+        hipLaunchKernelGGL(sq_mirror1_gen, dim3(aux_blocks), dim3(kBlock), 0, stream, S, F, W, 0ll);
+        SQ_HIP(hipGetLastError());
+        if (launch_trace(W, 1, 0, stream)) return 1;
+        hipLaunchKernelGGL(sq_mirror1_store, dim3(aux_blocks), dim3(kBlock), 0, stream, W, 0ll);
+        SQ_HIP(hipGetLastError());
+    }
     auto k0_of = [&](int i) { return i * batch; };
     auto kc_of = [&](int i) { return std::max(0, std::min(batch, F.samples - i * batch)); };
     int n_real = 0;
@@ -1193,8 +1225,11 @@ int launch_frame(sq_device_scene* s, const Frame& F, hipStream_t stream) {
             SQ_HIP(hipMemsetAsync(W.head[0], 0, 32 * sizeof(int32_t), stream));     // both dequeue cursors
             hipLaunchKernelGGL(sq_gen_bounce1, dim3(aux_blocks), dim3(kBlock), 0, stream, S, F, W, k0, kc);
             SQ_HIP(hipGetLastError());
+            const bool front = mirror_rides && i == 0;
+            if (front) hipLaunchKernelGGL(sq_mirror1_gen, dim3(aux_blocks), dim3(kBlock), 0, stream, S, F, W, (long long)W.slot_capacity);
             for (int level = 0; level < 2; ++level) {
-                if (launch_trace(W, kc, level)) return 1;
+                if (launch_trace(W, kc, level, stream, front && level == 0)) return 1;
+                if (front && level == 0) hipLaunchKernelGGL(sq_mirror1_store, dim3(aux_blocks), dim3(kBlock), 0, stream, W, (long long)W.slot_capacity);
                 if (level == 0) hipLaunchKernelGGL(sq_shade1, dim3(aux_blocks), dim3(kBlock), 0, stream, S, F, W, kc);
                 else hipLaunchKernelGGL(sq_shade2, dim3(aux_blocks), dim3(kBlock), 0, stream, S, F, W, kc);
                 SQ_HIP(hipGetLastError());
@@ -1212,6 +1247,39 @@ int launch_frame(sq_device_scene* s, const Frame& F, hipStream_t stream) {
         *e = s->events[next_event++];
         return 0;
     };
+    if (s->opt_overlap == 2) {
+        // Two pipelines: even batches run start to end on the caller's stream, odd batches on the second stream.  A trace
+        // launch needs a whole CU's LDS per workgroup, so the two tracks' launches do not share CUs: the later one's
+        // workgroups move in as the earlier one's finish, which fills the ramp-down of every launch (a ray takes
+        // 150-300 us from fetch to hit, and a launch ends when its slowest rays do) and overlaps the per-sample kernels
+        // of one track with the trace launches of the other.  Only the accumulation is ordered across tracks (src/Lib.hs:88).
+        std::vector<hipEvent_t> eAcc((size_t)n_real);
+        for (int i = 0; i < n_real; ++i) if (new_event(&eAcc[(size_t)i])) return 1;
+        hipEvent_t e_setup2, e_done2;
+        if (new_event(&e_setup2) || new_event(&e_done2)) return 1;
+        SQ_HIP(hipEventRecord(e_setup2, stream));
+        SQ_HIP(hipStreamWaitEvent(X, e_setup2, 0));
+        for (int i = 0; i < n_real; ++i) {
+            const hipStream_t on = (i & 1) ? X : stream;
+            const Work& V = Wt[i & 1];
+            const int k0 = k0_of(i), kc = kc_of(i);
+            SQ_HIP(hipMemsetAsync(V.head[0], 0, 32 * sizeof(int32_t), on));
+            hipLaunchKernelGGL(sq_gen_bounce1, dim3(aux_blocks), dim3(kBlock), 0, on, S, F, V, k0, kc);
+            SQ_HIP(hipGetLastError());
+            if (launch_trace(V, kc, 0, on)) return 1;
+            hipLaunchKernelGGL(sq_shade1, dim3(aux_blocks), dim3(kBlock), 0, on, S, F, V, kc);
+            SQ_HIP(hipGetLastError());
+            if (launch_trace(V, kc, 1, on)) return 1;
+            hipLaunchKernelGGL(sq_shade2, dim3(aux_blocks), dim3(kBlock), 0, on, S, F, V, kc);
+            if (i > 0) SQ_HIP(hipStreamWaitEvent(on, eAcc[(size_t)i - 1], 0));
+            hipLaunchKernelGGL(sq_accumulate, dim3(aux_blocks), dim3(kBlock), 0, on, F, V, kc, i == n_real - 1 ? 1 : 0);
+            SQ_HIP(hipGetLastError());
+            SQ_HIP(hipEventRecord(eAcc[(size_t)i], on));
+        }
+        SQ_HIP(hipEventRecord(e_done2, X));
+        SQ_HIP(hipStreamWaitEvent(stream, e_done2, 0));
+        return 0;
+    }
     // the four events of a batch: G = its rays are generated, T1 / T2 = a trace level is done, S1 = ray 2 is in the slots
     std::vector<hipEvent_t> eG((size_t)n_real), eT1((size_t)n_real), eS1((size_t)n_real), eT2((size_t)n_real);
     for (int i = 0; i < n_real; ++i) if (new_event(&eG[(size_t)i]) || new_event(&eT1[(size_t)i]) || new_event(&eS1[(size_t)i]) || new_event(&eT2[(size_t)i])) return 1;
@@ -1229,7 +1297,7 @@ int launch_frame(sq_device_scene* s, const Frame& F, hipStream_t stream) {
     };
     auto trace = [&](int i, int level) -> int {             // on the caller's stream
         SQ_HIP(hipStreamWaitEvent(stream, level == 0 ? eG[(size_t)i] : eS1[(size_t)i], 0));
-        if (launch_trace(Wt[i & 1], kc_of(i), level)) return 1;
+        if (launch_trace(Wt[i & 1], kc_of(i), level, stream)) return 1;
         SQ_HIP(hipEventRecord(level == 0 ? eT1[(size_t)i] : eT2[(size_t)i], stream));
         return 0;
     };
@@ -1328,8 +1396,9 @@ extern "C" int sq_set_option(sq_device_scene* s, const char* key, int64_t value)
     if (!std::strcmp(key, "profile")) { s->opt_profile = value ? 1 : 0; return 0; }
     if (!std::strcmp(key, "lds_node_kb")) { if (value < 0 || value > 128) return sq_set_error("lds_node_kb must be in 0..128"); s->opt_lds_node_kb = value; return 0; }
     if (!std::strcmp(key, "trace_blocks_per_cu")) { if (value < 0 || value > 8) return sq_set_error("trace_blocks_per_cu must be in 0..8"); s->opt_trace_blocks_per_cu = value; return 0; }
-    if (!std::strcmp(key, "overlap")) { s->opt_overlap = value ? 1 : 0; return 0; }
+    if (!std::strcmp(key, "overlap")) { if (value < 0 || value > 2) return sq_set_error("overlap must be 0, 1 or 2"); s->opt_overlap = value; return 0; }
     if (!std::strcmp(key, "pool")) { s->opt_pool = value ? 1 : 0; return 0; }
+    if (!std::strcmp(key, "guided")) { s->opt_guided = value ? 1 : 0; return 0; }
     if (!std::strcmp(key, "refill_min")) { if (value < 1 || value > 64) return sq_set_error("refill_min must be in 1..64"); s->opt_refill_min = value; return 0; }
     if (!std::strcmp(key, "flush_min")) { if (value < 0 || value > 64) return sq_set_error("flush_min must be in 0..64"); s->opt_flush_min = value; return 0; }
     if (!std::strcmp(key, "aux_blocks_per_cu")) { if (value < 0 || value > 16) return sq_set_error("aux_blocks_per_cu must be in 0..16"); s->opt_aux_blocks_per_cu = value; return 0; }

@@ -81,12 +81,19 @@ __device__ __forceinline__ bool slab(float lx, float ly, float lz, float hx, flo
 // operand is NaN (and in the sign of a zero result, which no comparison below can see).  When the ray's
 // origin, direction and 1/direction are all finite, (bound - o) * df is finite or +-inf, never NaN, so
 // both forms return the same Bool.  `safe` rays use this form; any other ray uses slab().
+// v_min_f32 / v_max_f32 / v_max3_f32 / v_min3_f32 written out: through the builtins the compiler first "canonicalises"
+// operands it cannot prove quiet (six extra v_max x,x per branch step); the instructions themselves need no such help,
+// and for the NaN-free operands of a safe ray they return the plain minimum / maximum.
+__device__ __forceinline__ float vmin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vmax3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float vmin3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 __device__ __forceinline__ bool slab_fast(float lx, float ly, float lz, float hx, float hy, float hz, f3 o, f3 df) {
     const float t1 = (lx - o.x) * df.x, t2 = (hx - o.x) * df.x;
     const float t3 = (ly - o.y) * df.y, t4 = (hy - o.y) * df.y;
     const float t5 = (lz - o.z) * df.z, t6 = (hz - o.z) * df.z;
-    const float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t1, t2), __builtin_fminf(t3, t4)), __builtin_fminf(t5, t6));
-    const float tmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t1, t2), __builtin_fmaxf(t3, t4)), __builtin_fmaxf(t5, t6));
+    const float tmin = vmax3(vmin(t1, t2), vmin(t3, t4), vmin(t5, t6));
+    const float tmax = vmin3(vmax(t1, t2), vmax(t3, t4), vmax(t5, t6));
     return tmax > 0 && tmin < tmax;
 }
 __device__ __forceinline__ bool finite3(f3 v) {

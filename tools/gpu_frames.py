@@ -9,6 +9,8 @@ import torch
 kv = dict(a.split("=") for a in sys.argv[1:])
 frames = int(kv.pop("frames", 2)); spp = int(kv.pop("spp", 256)); w = int(kv.pop("w", 1920)); h = int(kv.pop("h", 1080))
 which = kv.pop("scene", "obj")
+shard = tuple(int(x) for x in kv.pop("shard", "0,0,1").split(","))      # row_block,shard,n_shards (row_block 0 = whole frame)
+shard = (None, 0, 1) if shard[0] == 0 else shard
 if which == "obj":
     data = os.path.join(ROOT, "data")
     obj, sq, camt = (open(os.path.join(data, f), "rb").read() for f in ("scene.obj", "scene.sq", "camera"))
@@ -23,6 +25,6 @@ for k, v in kv.items():
     ds.set_option(k, int(v))
 ref = None
 for i in range(frames):
-    t = time.time(); _, r = ds.render_rows(cam, spp, w, h, want_avg=False); torch.cuda.synchronize()
+    t = time.time(); _, r = ds.render_rows(cam, spp, w, h, want_avg=False, shard=shard); torch.cuda.synchronize()
     dt = time.time() - t
     print(f"{which} {kv} frame {i}: {dt*1e3:.1f} ms -> {w*h*spp/dt/1e6:.0f} Msamples/s, image checksum {int(r.to(torch.int64).sum())}", flush=True)
