@@ -104,6 +104,7 @@ int  sq_get_stats(sq_device_scene* s, uint64_t* out, int32_t n, int32_t reset);
  *   "refill_min"         pooled kernel: idle lanes a wave collects before it fetches new rays (default 12)
  *   "flush_min"          pooled kernel: a trailing part-filled window of pairs runs at once from this many pairs on,
  *                        otherwise it waits one iteration for more (default 40)
+ *   "primary_resident"   1 = with a resident scene the primary rays are traced out of LDS too (default), 0 = from L2
  *   "guided"             1 = queue reservations shrink towards the end of a launch (default), 0 = fixed size
  *   "straggler_lanes"    pool = 0: lanes still traversing when a wave turns to its leaves (default 8)
  *   "trace_blocks_per_cu" streaming form: workgroups per CU (0 = as many as LDS allows, up to 4)

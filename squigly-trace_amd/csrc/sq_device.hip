@@ -428,6 +428,58 @@ __device__ __forceinline__ int wave_max(int v) {
     for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
     return v;
 }
+// Copies the resident form of the scene (sq_scene.h) into the workgroup's LDS and points N / G at it.  The caller syncs.
+template <int BLOCK>
+__device__ __forceinline__ void stage_resident_scene(const SceneView& S, int n_branches, char* lds, const TraceLds& L, ResidentNodes& N, ResidentTris& G) {
+    SQ_LDS v4f* lquads = to_lds<v4f>(lds + L.quads);
+    SQ_LDS v2i* lrefs = to_lds<v2i>(lds + L.refs);
+    SQ_LDS v4f* lv = to_lds<v4f>(lds + L.verts);
+    SQ_LDS v4us* lt = to_lds<v4us>(lds + L.trix);
+    for (int i = threadIdx.x; i < n_branches; i += BLOCK) {
+        const uint32_t* r = S.rbranch + 10 * (size_t)i;
+        lquads[2 * i] = v4f{ __uint_as_float(r[0]), __uint_as_float(r[1]), __uint_as_float(r[2]), __uint_as_float(r[3]) };
+        lquads[2 * i + 1] = v4f{ __uint_as_float(r[4]), __uint_as_float(r[5]), __uint_as_float(r[6]), __uint_as_float(r[7]) };
+        lrefs[i] = v2i{ (int)r[8], (int)r[9] };
+    }
+    for (int i = threadIdx.x; i < S.n_verts; i += BLOCK) { const float4 v = S.verts4[i]; lv[i] = v4f{ v.x, v.y, v.z, v.w }; }
+    for (int i = threadIdx.x; i < S.n_tris; i += BLOCK) {                  // vertex indices become byte offsets into the vertex table
+        const ushort4 t = S.trix[i];
+        lt[i] = v4us{ (unsigned short)(t.x * 16u), (unsigned short)(t.y * 16u), (unsigned short)(t.z * 16u), t.w };
+    }
+    N = ResidentNodes{ lquads, lrefs };
+    G = ResidentTris{ lt };
+    if ((uintptr_t)lv != 0) __builtin_trap();                              // the kernels that use this have no static LDS: dynamic LDS starts at address 0
+}
+
+// Primary rays with the scene in LDS (the resident form): same per-ray code as sq_primary, but a branch or triangle costs an
+// LDS read instead of an L2 round trip.  A primary ray is a chain of ~200 dependent reads, so on small frames -- one rank's
+// share of a frame at 8 ranks -- the launch is as long as that chain: 0.58 ms from L2, 0.1-0.2 ms from LDS.
+template <typename StackT>
+__global__ void __launch_bounds__(kResidentBlock) sq_primary_resident(const SceneView S, const Frame F, const Work W, int stack_cap) {
+    extern __shared__ float4 lds_raw[];
+    char* lds = reinterpret_cast<char*>(lds_raw);
+    const TraceLds L = trace_lds_layout(S.n_branches, true, S.n_verts, S.n_tris, kResidentBlock, stack_cap, (int)sizeof(StackT), false);
+    SQ_LDS StackT* stk = to_lds<StackT>(lds + L.stack) + threadIdx.x;
+    ResidentNodes N; ResidentTris G;
+    stage_resident_scene<kResidentBlock>(S, S.n_branches, lds, L, N, G);
+    __syncthreads();
+    const long long total = (long long)F.local_rows * F.h;
+    for (long long base = (long long)blockIdx.x * kResidentBlock; base < total; base += (long long)gridDim.x * kResidentBlock) {
+        const long long pix = base + threadIdx.x;
+        const bool in = pix < total;
+        Hit h0; h0.tri = -1; h0.t = 0;
+        if (in) {
+            int y, x; pixel_coords(F, pix, y, x);
+            h0 = trace_one(S, N, G, S.rroot, sq::mk(F.cam_pos[0], F.cam_pos[1], F.cam_pos[2]), primary_dir(F.cam_rot, F.w, F.h, y, x), stk, kResidentBlock);
+        }
+        const int a = wave_append(W.n_active, in && h0.tri >= 0);
+        if (a >= 0) {
+            W.px_pixel[a] = (int32_t)pix; W.px_t0[a] = h0.t; W.px_tri0[a] = h0.tri;
+            W.px_sum[3 * a] = 0.0f; W.px_sum[3 * a + 1] = 0.0f; W.px_sum[3 * a + 2] = 0.0f;
+        }
+    }
+}
+
 template <typename StackT, bool RESIDENT, int BLOCK, bool PROFILE, bool POOL>
 __global__ void __launch_bounds__(BLOCK) sq_trace_rays(const SceneView S, const TraceArgs A) {
     extern __shared__ float4 lds_raw[];
@@ -442,23 +494,7 @@ __global__ void __launch_bounds__(BLOCK) sq_trace_rays(const SceneView S, const 
     NodeSrc N; TriSrc G;
     uint32_t root_ref;
     if constexpr (RESIDENT) {                                         // stage the whole scene (coalesced loads)
-        SQ_LDS v2i* lrefs = to_lds<v2i>(lds + L.refs);
-        SQ_LDS v4f* lv = to_lds<v4f>(lds + L.verts);
-        SQ_LDS v4us* lt = to_lds<v4us>(lds + L.trix);
-        for (int i = threadIdx.x; i < A.n_lds; i += BLOCK) {
-            const uint32_t* r = S.rbranch + 10 * (size_t)i;
-            lquads[2 * i] = v4f{ __uint_as_float(r[0]), __uint_as_float(r[1]), __uint_as_float(r[2]), __uint_as_float(r[3]) };
-            lquads[2 * i + 1] = v4f{ __uint_as_float(r[4]), __uint_as_float(r[5]), __uint_as_float(r[6]), __uint_as_float(r[7]) };
-            lrefs[i] = v2i{ (int)r[8], (int)r[9] };
-        }
-        for (int i = threadIdx.x; i < S.n_verts; i += BLOCK) { const float4 v = S.verts4[i]; lv[i] = v4f{ v.x, v.y, v.z, v.w }; }
-        for (int i = threadIdx.x; i < S.n_tris; i += BLOCK) {              // vertex indices become byte offsets into the vertex table
-            const ushort4 t = S.trix[i];
-            lt[i] = v4us{ (unsigned short)(t.x * 16u), (unsigned short)(t.y * 16u), (unsigned short)(t.z * 16u), t.w };
-        }
-        N = ResidentNodes{ lquads, lrefs };
-        G = ResidentTris{ lt };
-        if ((uintptr_t)lv != 0) __builtin_trap();                          // the kernel has no static LDS, so its dynamic LDS starts at address 0
+        stage_resident_scene<BLOCK>(S, A.n_lds, lds, L, N, G);
         root_ref = S.rroot;
     } else {
         for (int i = threadIdx.x; i < 3 * A.n_lds; i += BLOCK) { const float4 q = S.branches[i]; lquads[i] = v4f{ q.x, q.y, q.z, q.w }; }
@@ -733,7 +769,7 @@ struct sq_device_scene {
     // second stream of the overlapped schedule (launch_frame) and its event pool
     hipStream_t aux = nullptr; std::vector<hipEvent_t> events;
     int64_t opt_overlap = 0, opt_aux_blocks_per_cu = 0;
-    int64_t opt_pool = 1, opt_refill_min = 12, opt_flush_min = 40, opt_guided = 1;
+    int64_t opt_pool = 1, opt_refill_min = 12, opt_flush_min = 40, opt_guided = 1, opt_primary_resident = 1;
 };
 
 namespace {
@@ -1153,9 +1189,6 @@ int launch_frame(sq_device_scene* s, const Frame& F, hipStream_t stream) {
     if (F.out_avg) SQ_HIP(hipMemsetAsync(F.out_avg, 0, (size_t)pixels * 3 * sizeof(float), stream));   // pixels whose primary ray misses: black
     if (F.out_rgb) SQ_HIP(hipMemsetAsync(F.out_rgb, 0, (size_t)pixels * 3, stream));
     SQ_HIP(hipMemsetAsync(W.n_active, 0, 128 * sizeof(int32_t), stream));
-    if (px_lds > 64 * 1024) SQ_HIP(hipFuncSetAttribute((const void*)sq_primary<StackT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)px_lds));
-    hipLaunchKernelGGL(sq_primary<StackT>, dim3((unsigned)px_blocks), dim3(kBlock), px_lds, stream, S, F, W);
-    SQ_HIP(hipGetLastError());
     // persistent trace kernel geometry.  Resident form: the whole scene (branches, leaves, unique vertices,
     // 16-bit indexed triangles) plus every lane's stack fits in the 160 KB of one CU -> one 1024-thread
     // workgroup per CU, no global traffic except ray fetch and hit store.  Streaming form otherwise.
@@ -1186,6 +1219,17 @@ int launch_frame(sq_device_scene* s, const Frame& F, hipStream_t stream) {
     }
     const size_t tr_lds = L.total;
     if (tr_lds > 64 * 1024) SQ_HIP(hipFuncSetAttribute(trace_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tr_lds));
+    // primary rays: once per pixel.  With a resident scene they are traced out of LDS as well.
+    if (resident && s->opt_primary_resident) {
+        const TraceLds Lp = trace_lds_layout(S.n_branches, true, S.n_verts, S.n_tris, kResidentBlock, stack_cap, (int)sizeof(StackT), false);
+        SQ_HIP(hipFuncSetAttribute((const void*)sq_primary_resident<StackT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Lp.total));
+        const long long need = (pixels + kResidentBlock - 1) / kResidentBlock;
+        hipLaunchKernelGGL(sq_primary_resident<StackT>, dim3((unsigned)std::min<long long>(s->n_cu, need)), dim3(kResidentBlock), Lp.total, stream, S, F, W, stack_cap);
+    } else {
+        if (px_lds > 64 * 1024) SQ_HIP(hipFuncSetAttribute((const void*)sq_primary<StackT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)px_lds));
+        hipLaunchKernelGGL(sq_primary<StackT>, dim3((unsigned)px_blocks), dim3(kBlock), px_lds, stream, S, F, W);
+    }
+    SQ_HIP(hipGetLastError());
     const int aux_blocks = s->n_cu * (int)(s->opt_aux_blocks_per_cu ? s->opt_aux_blocks_per_cu : 8);
     auto launch_trace = [&](const Work& W, int kc, int level, hipStream_t on, bool with_mirror_rays = false) -> int {
         // a launch with few slots (the per-pixel mirror rays) takes small reservations, or only a few waves get any
@@ -1399,6 +1443,7 @@ extern "C" int sq_set_option(sq_device_scene* s, const char* key, int64_t value)
     if (!std::strcmp(key, "overlap")) { if (value < 0 || value > 2) return sq_set_error("overlap must be 0, 1 or 2"); s->opt_overlap = value; return 0; }
     if (!std::strcmp(key, "pool")) { s->opt_pool = value ? 1 : 0; return 0; }
     if (!std::strcmp(key, "guided")) { s->opt_guided = value ? 1 : 0; return 0; }
+    if (!std::strcmp(key, "primary_resident")) { s->opt_primary_resident = value ? 1 : 0; return 0; }
     if (!std::strcmp(key, "refill_min")) { if (value < 1 || value > 64) return sq_set_error("refill_min must be in 1..64"); s->opt_refill_min = value; return 0; }
     if (!std::strcmp(key, "flush_min")) { if (value < 0 || value > 64) return sq_set_error("flush_min must be in 0..64"); s->opt_flush_min = value; return 0; }
     if (!std::strcmp(key, "aux_blocks_per_cu")) { if (value < 0 || value > 16) return sq_set_error("aux_blocks_per_cu must be in 0..16"); s->opt_aux_blocks_per_cu = value; return 0; }

@@ -569,17 +569,21 @@ __device__ __forceinline__ void trav_unwind(Trav& T, const NodeSrc& N, const Tri
 }
 
 // Whole query, one ray per lane (used where rays of a wave are coherent: primary and shadow rays).
-template <typename NodeSrc, typename StackT>
-__device__ __forceinline__ Hit trace_one(const SceneView& S, const NodeSrc& N, f3 o, f3 d, SQ_LDS StackT* stk, int stride) {
-    const GlobalTris G{ S.tris, S.leaves, S.packed_leaves != 0, false };
+template <typename NodeSrc, typename TriSrc, typename StackT>
+__device__ __forceinline__ Hit trace_one(const SceneView& S, const NodeSrc& N, const TriSrc& G, uint32_t root_ref, f3 o, f3 d, SQ_LDS StackT* stk, int stride) {
     Trav T;
-    trav_begin(T, S, S.root_ref, o, d);
+    trav_begin(T, S, root_ref, o, d);
     while (T.mode != M_DONE) {
         while (T.mode == M_DESCEND) trav_descend(T, N, stk, stride);
         if (T.mode == M_LEAF) trav_leaf(T, G);
         while (T.mode == M_UNWIND) trav_unwind(T, N, G, stk, stride);
     }
     return T.R;
+}
+template <typename NodeSrc, typename StackT>
+__device__ __forceinline__ Hit trace_one(const SceneView& S, const NodeSrc& N, f3 o, f3 d, SQ_LDS StackT* stk, int stride) {
+    const GlobalTris G{ S.tris, S.leaves, S.packed_leaves != 0, false };
+    return trace_one(S, N, G, S.root_ref, o, d, stk, stride);
 }
 
 }  // namespace sqd
