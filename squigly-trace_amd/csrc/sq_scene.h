@@ -266,11 +266,14 @@ struct HybridNodes {            // first n_lds branches (top of the tree) in LDS
     // kBoxInRegisters = true carries the traversal box in six registers (a child's box is its parent's with one plane
     // replaced, src/BIH.hs:130-141 -- the same floats as the precomputed boxes), so that a visit reads ONE quad (planes,
     // axis, children) instead of three and only a return into a branch re-reads that branch's box: 45 % fewer branch
-    // loads.  Measured (MI355X, bits unchanged, 49 GPU tests): 82k-triangle scene 62.0 -> 64.0 ms, 1M-triangle scene
-    // 115 -> 119 ms with the pooled kernel (+3 % only with pool = 0).  The counters say why: these scenes are bound by
+    // loads.  Measured (one MI355X, both builds in the same run, bits unchanged): 82k-triangle scene 54.8 -> 57.6 ms,
+    // 1M-triangle scene 105.7 -> 107.5 ms, scene.obj streamed 86.5 -> 89.0 ms.  The counters say why: these scenes are bound by
     // VALU issue, not by branch loads (4.2 cycles per VALU instruction per SIMD on the 82k scene, L2 hit rate 99.9 %,
-    // profiles/r02a_pmc_c3.txt), and tracking the box costs VALU.  Left off.
-    static constexpr bool kBoxInRegisters = false;
+    // profiles/r02a_pmc_c3.txt), and tracking the box costs VALU.  Left off (-DSQ_BOX_IN_REGISTERS=1 builds it).
+#ifndef SQ_BOX_IN_REGISTERS
+#define SQ_BOX_IN_REGISTERS 0
+#endif
+    static constexpr bool kBoxInRegisters = SQ_BOX_IN_REGISTERS != 0;
     const SQ_LDS v4f* l; const float4* g; uint32_t n_lds;
     __device__ __forceinline__ BranchData load(uint32_t b) const {
         if (b < n_lds) return unpack_branch(l[3 * b], l[3 * b + 1], l[3 * b + 2]);
