@@ -370,3 +370,17 @@ def test_loader_against_a_regex_parser(sqt):
         for g, (_, vals) in zip(gm, mats):
             flat = [g["reflective"], *g["surf"], g["emissive"], *g["emit"]]
             assert np.array_equal(np.array(flat, np.float32).view(np.uint32), np.array(vals, np.float32).view(np.uint32))
+
+
+def test_bench_without_enough_devices_exits_non_zero():
+    """The driver calls `python bench.py --gpus N`.  Without N visible HIP devices (none at all in the CPU container) the
+    launcher must fail with a message and print no JSON line: never a silent 1-GPU number labelled N."""
+    import subprocess
+    import sys
+    for n in ("2", "8"):
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", n, "--steps", "1", "--warmup", "0"],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+        import torch
+        if torch.cuda.device_count() >= int(n):
+            continue                                    # a box that really has that many devices runs the benchmark instead
+        assert p.returncode == 2 and "device" in p.stderr and p.stdout.strip() == ""
