@@ -90,8 +90,9 @@ int sq_render_rows_device(sq_device_scene* s, const sq_camera* cam, int32_t samp
  * average duration in ms over the launches since the last reset, and the launch count. */
 int  sq_kernel_timing(sq_device_scene* s, double* avg_ms, int64_t* launches, const char** kernel_name);
 void sq_kernel_timing_reset(sq_device_scene* s);
-/* Cumulative statistics of the trace kernel since the last reset (synchronises the device):
- * out[0] = rays traced; out[1..8] = lane-occupancy counters, filled only with option "profile" = 1. */
+/* Cumulative statistics of the trace kernel since the last reset (synchronises the device), n <= 32:
+ * out[0] = rays traced; out[1..23] = lane-occupancy counters, rare-path counts and per-section wave cycles of the
+ * profile build, filled only with option "profile" = 1 (tools/gpu_pool.py prints them). */
 int  sq_get_stats(sq_device_scene* s, uint64_t* out, int32_t n, int32_t reset);
 /* Tunables; every setting produces identical bits.  Keys:
  *   "variant"            1 = one-lane-per-pixel kernel, 2 = wavefront pipeline (default)
@@ -110,8 +111,11 @@ int  sq_get_stats(sq_device_scene* s, uint64_t* out, int32_t n, int32_t reset);
  *   "trace_blocks_per_cu" streaming form: workgroups per CU (0 = as many as LDS allows, up to 4)
  *   "timing"             1 = bracket the dominant kernel with hipEvents for sq_kernel_timing (default 0)
  *   "profile"            1 = lane-occupancy counters in sq_get_stats (slower)
- *   "overlap"            1 = two sample batches in flight: trace launches on the caller's stream, the per-sample
- *                        kernels beside them on an internal stream (+3 % measured; default 0)
+ *   "overlap"            0 = one stream (default; per-kernel durations stay clean for the roofline)
+ *                        1 = two sample batches in flight: trace launches on the caller's stream, the per-sample
+ *                            kernels beside them on an internal stream
+ *                        2 = two pipelines: even and odd sample batches run start to end on two streams, so that one
+ *                            track's launches fill the other's ramp-downs (+1.9 % on the headline frame)
  *   "aux_blocks_per_cu"  workgroups per CU of the per-sample kernels (0 = default 8) */
 int  sq_set_option(sq_device_scene* s, const char* key, int64_t value);
 
