@@ -115,15 +115,26 @@ def time_other_config(sqt, torch, name, make, w, h, spp, traffic_key):
            "kernel": kname, "kernel_ms_total": round(kern_ms * launches, 1), "launches": launches}
     prof = load_profile("latest_other_configs.json")
     if prof and traffic_key in prof and kern_ms > 0:
-        p = prof[traffic_key]      # per frame, sq_trace_rays launches: separate --pmc passes (tools/collect_profiles.sh)
+        p = prof[traffic_key]      # per frame, sq_trace_rays launches: separate --pmc passes (tools/collect_profiles.py)
+        secs = kern_ms * launches * 1e-3
         traffic = p["hbm_bytes_per_frame"]
-        out["roofline"] = {"bound": "hbm", "achieved": round(traffic / (kern_ms * launches * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
-                           "unit": "GB/s", "frac": round(traffic / (kern_ms * launches * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                           "traffic": traffic,
-                           "what": "memory-side bytes of the trace launches of one frame (FETCH_SIZE x 2 + WRITE_SIZE, Infinity-Cache hits "
-                                   "included: the guide's counters cannot separate them) / their measured duration",
-                           "vmem_load_wave_instructions_per_ray": round(p["vmem_rd_per_frame"] / max(rays, 1), 2) if p.get("vmem_rd_per_frame") else None,
-                           "l2_hit_rate": p.get("l2_hit_rate")}
+        mem = {"achieved": round(traffic / secs / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(traffic / secs / 1e9 / HBM_PEAK_GBS, 4),
+               "what": "memory-side bytes of the trace launches of one frame (FETCH_SIZE x 2 + WRITE_SIZE; Infinity-Cache hits are "
+                       "included, the guide's counters cannot separate them) / their measured duration",
+               "l2_hit_rate": p.get("l2_hit_rate"),
+               "vmem_load_wave_instructions_per_ray": round(p["vmem_rd_per_frame"] / max(rays, 1), 2) if p.get("vmem_rd_per_frame") else None}
+        valu = None
+        if p.get("SQ_INSTS_VALU"):
+            lane_util = p["SQ_THREAD_CYCLES_VALU"] / (64.0 * p["SQ_ACTIVE_INST_VALU"])
+            issue = p["SQ_INSTS_VALU"] / secs / (N_SIMD * CLOCK_HZ / 2)
+            achieved = p["SQ_INSTS_VALU"] * 64 * lane_util / secs / 1e12
+            valu = {"achieved": round(achieved, 2), "peak": round(VALU_PEAK_TLANEOPS, 1), "unit": "Tlane-op/s", "frac": round(achieved / VALU_PEAK_TLANEOPS, 4),
+                    "valu_issue_frac": round(issue, 4), "valu_lane_utilisation": round(lane_util, 4)}
+        # the larger fraction names the bound; both are reported
+        if valu and valu["frac"] >= mem["frac"]:
+            out["roofline"] = {"bound": "valu", **valu, "traffic": traffic, "memory": mem}
+        else:
+            out["roofline"] = {"bound": "hbm", **{k: mem[k] for k in ("achieved", "peak", "unit", "frac")}, "traffic": traffic, "memory": mem, "valu": valu}
     return out
 
 

@@ -98,6 +98,7 @@ for key, scene, spp in (("c3", "blob6", 512), ("c5", "hf708", 256)):
         other[key] = {"scene": scene, "spp": spp, "hbm_bytes_per_frame": (f * 2 + wv) * 1024, "vmem_rd_per_frame": rd,
                       "l2_hit_rate": round(hit / (hit + miss), 4) if hit is not None and miss is not None and hit + miss > 0 else None,
                       "wait_fraction_of_wave_cycles": round(wa / wc, 3) if wa and wc else None,
+                      **{c: trace_sum(tots, c)[0] for c in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_BUSY_CYCLES")},
                       "note": "FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE, KB -> bytes; separate --pmc passes"}
     json.dump(other, open(opath, "w"), indent=1)
     print(key, json.dumps(other.get(key)), flush=True)
