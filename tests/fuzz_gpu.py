@@ -246,7 +246,7 @@ def run_case(seed, kinds=12):
         for variant in (2, 1):
             ds.set_option("variant", variant)
             if BIG:
-                ds.set_option("overlap", int(rng.integers(0, 2)))
+                ds.set_option("overlap", int(rng.integers(0, 3)))
                 ds.set_option("slots", int(rng.choice([w * h, 3 * w * h + 17, 1 << 22])))
             a, r = ds.render_rows(cam_p, spp, w, h, cast=cast)
             torch.cuda.synchronize()
