@@ -4,7 +4,7 @@
 //   camera-ray generation            src/Lib.hs:107-114                      sq_primary
 //   RNG + bounce (scatter / mirror)  src/Lib.hs:133-134,155-198              sq_gen_bounce1, sq_shade1
 //   BIH traversal + Moller-Trumbore  src/BIH.hs:101-141, Geometry.hs:117-177 sq_trace_rays (dominant kernel)
-//   emissive shade, radiance fold    src/Lib.hs:135-137                      sq_shade1, sq_shade2
+//   emissive shade, radiance fold    src/Lib.hs:135-137                      sq_shade1, sq_accumulate
 //   ordered per-pixel accumulation   src/Lib.hs:85-88                        sq_accumulate
 //   atan tonemap                     src/Lib.hs:93-104                       sq_accumulate
 //
@@ -349,29 +349,31 @@ __global__ void __launch_bounds__(kBlock) sq_shade1(const SceneView S, const Fra
     }
 }
 
-// After ray 2: L2 = s2*0 + e2 (or black), L1 = s1*L2 + e1, L0 = s0*L1 + e0   (src/Lib.hs:135-137)
-__global__ void __launch_bounds__(kBlock) sq_shade2(const SceneView S, const Frame F, const Work W, int k_count) {
-    const int A = *W.n_active;
-    const unsigned total = (unsigned)A * (unsigned)k_count;
-    for (unsigned sid = blockIdx.x * kBlock + threadIdx.x; sid < total; sid += gridDim.x * kBlock) {
-        if (W.state[sid] != kRay2) continue;                            // 8 % of the slots on the headline frame
-        const int tri1 = __float_as_int(W.dir[sid].w), tri2 = W.hit[sid].y;
-        f3 L2 = sq::mk(0, 0, 0);
-        if (tri2 >= 0) { const Surface s2 = surface_of(S, tri2); L2 = s2.surf * sq::mk(0, 0, 0) + s2.emit; }
-        const Surface s1 = surface_of(S, tri1), s0 = surface_of(S, W.px_tri0[sid % (unsigned)A]);
-        const f3 L1 = s1.surf * L2 + s1.emit;
-        store_rad(W, sid, s0.surf * L1 + s0.emit);
-    }
+// After ray 2: L2 = s2*0 + e2 (or black), L1 = s1*L2 + e1, L0 = s0*L1 + e0   (src/Lib.hs:135-137).
+// Not a kernel of its own: the 8 % of the slots that still hold a second bounce ray are folded where their radiance is
+// consumed (sq_accumulate), which saves a pass over every slot's state and the round trip of their radiance through HBM.
+__device__ __forceinline__ f3 shade2_radiance(const SceneView& S, const Work& W, long long sid, const Surface& s0) {
+    const int tri1 = __float_as_int(W.dir[sid].w), tri2 = W.hit[sid].y;
+    f3 L2 = sq::mk(0, 0, 0);
+    if (tri2 >= 0) { const Surface s2 = surface_of(S, tri2); L2 = s2.surf * sq::mk(0, 0, 0) + s2.emit; }
+    const Surface s1 = surface_of(S, tri1);
+    const f3 L1 = s1.surf * L2 + s1.emit;
+    return s0.surf * L1 + s0.emit;
 }
 
 // sum outcomes, in sample order (src/Lib.hs:88); on the last batch: avg, tonemap, store.
-__global__ void __launch_bounds__(kBlock) sq_accumulate(const Frame F, const Work W, int k_count, int last) {
+__global__ void __launch_bounds__(kBlock) sq_accumulate(const SceneView S, const Frame F, const Work W, int k_count, int last) {
     const int A = *W.n_active;
     for (int a = blockIdx.x * kBlock + threadIdx.x; a < A; a += gridDim.x * kBlock) {
         f3 sum = sq::mk(W.px_sum[3 * a], W.px_sum[3 * a + 1], W.px_sum[3 * a + 2]);
+        const Surface s0 = surface_of(S, W.px_tri0[a]);
+        uint8_t st = k_count > 0 ? W.state[a] : kDone;                 // the next slot's state is requested one sample ahead
         for (int k = 0; k < k_count; ++k) {
             const long long sid = (long long)k * A + a;
-            sum = sum + sq::mk(W.rad[3 * sid], W.rad[3 * sid + 1], W.rad[3 * sid + 2]);
+            const uint8_t cur = st;
+            if (k + 1 < k_count) st = W.state[sid + A];
+            const f3 rad = (cur == kRay2) ? shade2_radiance(S, W, sid, s0) : sq::mk(W.rad[3 * sid], W.rad[3 * sid + 1], W.rad[3 * sid + 2]);
+            sum = sum + rad;
         }
         if (!last) { W.px_sum[3 * a] = sum.x; W.px_sum[3 * a + 1] = sum.y; W.px_sum[3 * a + 2] = sum.z; continue; }
         const f3 avg = sq::scale(1 / (float)F.samples, sum);
@@ -1275,10 +1277,9 @@ int launch_frame(sq_device_scene* s, const Frame& F, hipStream_t stream) {
                 if (launch_trace(W, kc, level, stream, front && level == 0)) return 1;
                 if (front && level == 0) hipLaunchKernelGGL(sq_mirror1_store, dim3(aux_blocks), dim3(kBlock), 0, stream, W, (long long)W.slot_capacity);
                 if (level == 0) hipLaunchKernelGGL(sq_shade1, dim3(aux_blocks), dim3(kBlock), 0, stream, S, F, W, kc);
-                else hipLaunchKernelGGL(sq_shade2, dim3(aux_blocks), dim3(kBlock), 0, stream, S, F, W, kc);
                 SQ_HIP(hipGetLastError());
             }
-            hipLaunchKernelGGL(sq_accumulate, dim3(aux_blocks), dim3(kBlock), 0, stream, F, W, kc, (k0 + kc >= F.samples) ? 1 : 0);
+            hipLaunchKernelGGL(sq_accumulate, dim3(aux_blocks), dim3(kBlock), 0, stream, S, F, W, kc, (k0 + kc >= F.samples) ? 1 : 0);
             SQ_HIP(hipGetLastError());
         }
         return 0;
@@ -1314,9 +1315,8 @@ int launch_frame(sq_device_scene* s, const Frame& F, hipStream_t stream) {
             hipLaunchKernelGGL(sq_shade1, dim3(aux_blocks), dim3(kBlock), 0, on, S, F, V, kc);
             SQ_HIP(hipGetLastError());
             if (launch_trace(V, kc, 1, on)) return 1;
-            hipLaunchKernelGGL(sq_shade2, dim3(aux_blocks), dim3(kBlock), 0, on, S, F, V, kc);
             if (i > 0) SQ_HIP(hipStreamWaitEvent(on, eAcc[(size_t)i - 1], 0));
-            hipLaunchKernelGGL(sq_accumulate, dim3(aux_blocks), dim3(kBlock), 0, on, F, V, kc, i == n_real - 1 ? 1 : 0);
+            hipLaunchKernelGGL(sq_accumulate, dim3(aux_blocks), dim3(kBlock), 0, on, S, F, V, kc, i == n_real - 1 ? 1 : 0);
             SQ_HIP(hipGetLastError());
             SQ_HIP(hipEventRecord(eAcc[(size_t)i], on));
         }
@@ -1354,8 +1354,7 @@ int launch_frame(sq_device_scene* s, const Frame& F, hipStream_t stream) {
     };
     auto finish = [&](int i) -> int {                       // on X, in batch order: the per-pixel sum is ordered (src/Lib.hs:88)
         SQ_HIP(hipStreamWaitEvent(X, eT2[(size_t)i], 0));
-        hipLaunchKernelGGL(sq_shade2, dim3(aux_blocks), dim3(kBlock), 0, X, S, F, Wt[i & 1], kc_of(i));
-        hipLaunchKernelGGL(sq_accumulate, dim3(aux_blocks), dim3(kBlock), 0, X, F, Wt[i & 1], kc_of(i), i == n_real - 1 ? 1 : 0);
+        hipLaunchKernelGGL(sq_accumulate, dim3(aux_blocks), dim3(kBlock), 0, X, S, F, Wt[i & 1], kc_of(i), i == n_real - 1 ? 1 : 0);
         SQ_HIP(hipGetLastError());
         if (i + 2 < n_real) return gen(i + 2);              // the track is free again
         return 0;
