@@ -645,6 +645,12 @@ __global__ void __launch_bounds__(BLOCK) sq_trace_rays(const SceneView S, const 
                     tri[k] = p + lane_pull(tb, src);
                     po[k] = sq::mk(lane_pull(T.o.x, src), lane_pull(T.o.y, src), lane_pull(T.o.z, src));
                     pd[k] = sq::mk(lane_pull(T.d.x, src), lane_pull(T.d.y, src), lane_pull(T.d.z, src));
+#ifdef SQ_EXTRA_PULLS   // timing experiment only (results unchanged): what do N more ds_bpermute per window cost, with no VALU attached?
+                    { int sink;
+#pragma unroll
+                      for (int e = 0; e < SQ_EXTRA_PULLS; ++e) asm volatile("ds_bpermute_b32 %0, %1, %2" : "=v"(sink) : "v"(src), "v"(tri[k]));
+                      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+#endif
                     hit[k] = p < P;                                         // so far: the pair exists
                     if (!hit[k]) tri[k] = 0;                                // lanes past the last pair test triangle 0 and drop the answer
                 }
