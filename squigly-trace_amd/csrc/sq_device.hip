@@ -215,29 +215,35 @@ __device__ __forceinline__ void store_rad(const Work& W, long long sid, f3 L) {
 }
 
 // Depth-0 bounce of every sample of the batch: RNG, bounceRay, ray 1 into slot sid (src/Lib.hs:133-134).
+// One thread per active pixel (blockIdx.y splits the samples of a pixel when a frame has few pixels): everything that is
+// the same for every sample of a pixel -- the pixel's coordinates, primary direction, hit point, surface, seed base -- is
+// computed once, not 256 times; consecutive threads still write consecutive slots (sid = k * A + a).
 __global__ void __launch_bounds__(kBlock) sq_gen_bounce1(const SceneView S, const Frame F, const Work W, int k_base, int k_count) {
     const int A = *W.n_active;
-    const unsigned total = (unsigned)A * (unsigned)k_count;             // <= slots <= 2^29: 32-bit index arithmetic
-    for (unsigned sid = blockIdx.x * kBlock + threadIdx.x; sid < total; sid += gridDim.x * kBlock) {
-        const int kl = (int)(sid / (unsigned)A), a = (int)(sid - (unsigned)kl * (unsigned)A), k = k_base + kl;
+    for (int a = blockIdx.x * kBlock + threadIdx.x; a < A; a += gridDim.x * kBlock) {
         const Pixel0 P = load_pixel0(S, F, W, a);
-        if (absorbs(S, P.s0)) {
-            store_rad(W, sid, P.s0.surf * sq::mk(0, 0, 0) + P.s0.emit);
-            W.state[sid] = kDone;
-            continue;
-        }
+        const bool absorbing = absorbs(S, P.s0);
+        const f3 rad_absorbing = P.s0.surf * sq::mk(0, 0, 0) + P.s0.emit;
         const long long rix = (long long)F.samples * ((long long)P.x + (long long)P.y * (long long)F.w);   // src/Lib.hs:85
-        uint32_t n0, n1, n2;
-        sq::tfgen3(rix + k, n0, n1, n2);                                // mkTFGen (rix + k), src/Lib.hs:86
-        W.rng12[sid] = make_uint2(n1, n2);
-        if (!scatters(P.s0, n0)) {                                      // mirror: traced once per pixel (sq_mirror1_*)
-            W.state[sid] = kMirror;
-            continue;
+        for (int kl = blockIdx.y; kl < k_count; kl += gridDim.y) {
+            const long long sid = (long long)kl * A + a;
+            if (absorbing) {
+                store_rad(W, sid, rad_absorbing);
+                W.state[sid] = kDone;
+                continue;
+            }
+            uint32_t n0, n1, n2;
+            sq::tfgen3(rix + (k_base + kl), n0, n1, n2);                // mkTFGen (rix + k), src/Lib.hs:86
+            W.rng12[sid] = make_uint2(n1, n2);
+            if (!scatters(P.s0, n0)) {                                  // mirror: traced once per pixel (sq_mirror1_*)
+                W.state[sid] = kMirror;
+                continue;
+            }
+            const f3 d1 = scatter_dir(P.d0, P.s0, n0, n1);
+            W.state[sid] = kRay1;
+            W.org[sid] = make_float4(P.p0.x, P.p0.y, P.p0.z, 0.0f);
+            W.dir[sid] = make_float4(d1.x, d1.y, d1.z, 0.0f);
         }
-        const f3 d1 = scatter_dir(P.d0, P.s0, n0, n1);
-        W.state[sid] = kRay1;
-        W.org[sid] = make_float4(P.p0.x, P.p0.y, P.p0.z, 0.0f);
-        W.dir[sid] = make_float4(d1.x, d1.y, d1.z, 0.0f);
     }
 }
 
@@ -267,85 +273,81 @@ __global__ void __launch_bounds__(kBlock) sq_mirror1_store(const Work W, long lo
 }
 
 // After ray 1: a miss finishes the sample; a hit either finishes it (absorbing surface) or puts ray 2 in the slot.
+// One thread per active pixel, like sq_gen_bounce1: the primary surface, the hit point and the pixel's mirror ray and its hit
+// are per-pixel values.  It waits on memory two thirds of its time, so a slot's state byte decides what else is read (nothing
+// for a finished slot, the generator words for a mirrored one, ray and hit for a traced one), the state and generator words
+// are requested two samples ahead and the rest one sample ahead.
 __global__ void __launch_bounds__(kBlock) sq_shade1(const SceneView S, const Frame F, const Work W, int k_count) {
     const int A = *W.n_active;
-    const unsigned total = (unsigned)A * (unsigned)k_count;
-    // Memory-bound (it waits on memory two thirds of its time): a slot's state byte decides what else is read --
-    // nothing for a finished slot, the generator words for a mirrored one (its ray and hit are the pixel's), everything
-    // for a traced one -- and the state and generator words of the NEXT slot are requested before this one is worked on.
-    // Two slots ahead: its state byte and generator words.  One slot ahead: what that state says is needed (ray and
-    // hit of a traced slot; the pixel's mirror hit of a mirrored one) and the primary triangle.  Then the slot itself.
     struct First { uint8_t st; uint2 r; };
-    struct Second { float4 org, dir; int2 hit; int a, tri0; };
-    auto first = [&](unsigned sid) { First f; f.st = W.state[sid]; f.r = W.rng12[sid]; return f; };
-    auto second = [&](unsigned sid, uint8_t st) {
-        Second q{};
-        if (st == kDone) return q;
-        q.a = (int)(sid % (unsigned)A); q.tri0 = W.px_tri0[q.a];
-        if (st == kMirror) q.hit = make_int2(__float_as_int(W.px_mt[q.a]), W.px_mtri[q.a]);
-        else { q.org = W.org[sid]; q.dir = W.dir[sid]; q.hit = W.hit[sid]; }
-        return q;
-    };
-    const unsigned stride = gridDim.x * kBlock;
-    unsigned sid = blockIdx.x * kBlock + threadIdx.x;
-    First f1{}, f2{}; Second q1{};
-    if (sid < total) { f1 = first(sid); q1 = second(sid, f1.st); }
-    if (sid + stride < total) f2 = first(sid + stride);
-    for (; sid < total; sid += stride) {
-        const First cur = f1; const Second q = q1;
-        f1 = f2;
-        if (sid + stride < total) q1 = second(sid + stride, f1.st);
-        if (sid + 2 * stride < total && sid + 2 * stride > sid) f2 = first(sid + 2 * stride);
-        if (cur.st == kDone) continue;
-        const uint2 r = cur.r;
-        const int a = q.a, tri0 = q.tri0;
-        const Surface s0 = surface_of(S, tri0);                         // every finished path folds it in
-        f3 d1, p0;
-        const int2 hit = q.hit;
-        if (cur.st == kMirror) {                                        // the pixel's mirror ray and its hit
-            const Pixel0 P = load_pixel0(S, F, W, a);
-            d1 = mirror_dir(P.d0, P.s0); p0 = P.p0;
-        } else {
-            d1 = sq::mk(q.dir.x, q.dir.y, q.dir.z); p0 = sq::mk(q.org.x, q.org.y, q.org.z);
-        }
-        const int tri1 = hit.y;
-        if (tri1 < 0) {                                                 // raytrace ... 1 = black
-            store_rad(W, sid, s0.surf * sq::mk(0, 0, 0) + s0.emit);
-            W.state[sid] = kDone;
-            continue;
-        }
-        const Surface s1 = surface_of(S, tri1);
-        if (absorbs(S, s1)) {
-            const f3 L1 = s1.surf * sq::mk(0, 0, 0) + s1.emit;
-            store_rad(W, sid, s0.surf * L1 + s0.emit);
-            W.state[sid] = kDone;
-            continue;
-        }
-        const f3 p1 = p0 + sq::scale(__int_as_float(hit.x), d1);
-        const f3 d2 = bounce_dir(d1, s1, r.x, r.y);                     // gen advanced by one: x = u = p(n1), v = p(n2)
-        // Ray 2 is the last one: all it contributes is L2 = s2*0 + e2, the emission of whatever it hits
-        // (src/Lib.hs:129,135-137).  Whatever the traversal returns is a triangle that mollerTrumbore accepted
-        // for this very ray, so if the SAME function rejects every emissive triangle, the result is a
-        // non-emissive hit or a miss, and L2 is exactly (+0,+0,+0) either way (materials are finite).
-        // Only rays that could reach an emitter are traced.
-        if (S.n_emitters >= 0) {
-            bool may_reach = false;
-            for (int j = 0; j < S.n_emitters && !may_reach; ++j) {
-                const int et = S.emitters[j];
-                const float* tp = S.tris + 9 * (size_t)et;
-                float t_unused;
-                may_reach = moller_trumbore(p1, d2, sq::mk(tp[0], tp[1], tp[2]), sq::mk(tp[3], tp[4], tp[5]), sq::mk(tp[6], tp[7], tp[8]), t_unused);
+    struct Second { float4 org, dir; int2 hit; };
+    for (int a = blockIdx.x * kBlock + threadIdx.x; a < A; a += gridDim.x * kBlock) {
+        const Pixel0 P = load_pixel0(S, F, W, a);
+        const Surface& s0 = P.s0;
+        const f3 d1_mirror = mirror_dir(P.d0, P.s0);
+        const int2 hit_mirror = make_int2(__float_as_int(W.px_mt[a]), W.px_mtri[a]);
+        const int step = gridDim.y;
+        auto first = [&](int kl) { First f; const long long sid = (long long)kl * A + a; f.st = W.state[sid]; f.r = W.rng12[sid]; return f; };
+        auto second = [&](int kl, uint8_t st) {
+            Second q{};
+            if (st == kRay1) { const long long sid = (long long)kl * A + a; q.org = W.org[sid]; q.dir = W.dir[sid]; q.hit = W.hit[sid]; }
+            return q;
+        };
+        int kl = blockIdx.y;
+        First f1{}, f2{}; Second q1{};
+        if (kl < k_count) { f1 = first(kl); q1 = second(kl, f1.st); }
+        if (kl + step < k_count) f2 = first(kl + step);
+        for (; kl < k_count; kl += step) {
+            const First cur = f1; const Second q = q1;
+            f1 = f2;
+            if (kl + step < k_count) q1 = second(kl + step, f1.st);
+            if (kl + 2 * step < k_count) f2 = first(kl + 2 * step);
+            if (cur.st == kDone) continue;
+            const long long sid = (long long)kl * A + a;
+            const uint2 r = cur.r;
+            f3 d1, p0;
+            int2 hit;
+            if (cur.st == kMirror) { d1 = d1_mirror; p0 = P.p0; hit = hit_mirror; }          // the pixel's mirror ray and its hit
+            else { d1 = sq::mk(q.dir.x, q.dir.y, q.dir.z); p0 = sq::mk(q.org.x, q.org.y, q.org.z); hit = q.hit; }
+            const int tri1 = hit.y;
+            if (tri1 < 0) {                                             // raytrace ... 1 = black
+                store_rad(W, sid, s0.surf * sq::mk(0, 0, 0) + s0.emit);
+                W.state[sid] = kDone;
+                continue;
             }
-            if (!may_reach) {
+            const Surface s1 = surface_of(S, tri1);
+            if (absorbs(S, s1)) {
                 const f3 L1 = s1.surf * sq::mk(0, 0, 0) + s1.emit;
                 store_rad(W, sid, s0.surf * L1 + s0.emit);
                 W.state[sid] = kDone;
                 continue;
             }
+            const f3 p1 = p0 + sq::scale(__int_as_float(hit.x), d1);
+            const f3 d2 = bounce_dir(d1, s1, r.x, r.y);                 // gen advanced by one: x = u = p(n1), v = p(n2)
+            // Ray 2 is the last one: all it contributes is L2 = s2*0 + e2, the emission of whatever it hits
+            // (src/Lib.hs:129,135-137).  Whatever the traversal returns is a triangle that mollerTrumbore accepted
+            // for this very ray, so if the SAME function rejects every emissive triangle, the result is a
+            // non-emissive hit or a miss, and L2 is exactly (+0,+0,+0) either way (materials are finite).
+            // Only rays that could reach an emitter are traced.
+            if (S.n_emitters >= 0) {
+                bool may_reach = false;
+                for (int j = 0; j < S.n_emitters && !may_reach; ++j) {
+                    const int et = S.emitters[j];
+                    const float* tp = S.tris + 9 * (size_t)et;
+                    float t_unused;
+                    may_reach = moller_trumbore(p1, d2, sq::mk(tp[0], tp[1], tp[2]), sq::mk(tp[3], tp[4], tp[5]), sq::mk(tp[6], tp[7], tp[8]), t_unused);
+                }
+                if (!may_reach) {
+                    const f3 L1 = s1.surf * sq::mk(0, 0, 0) + s1.emit;
+                    store_rad(W, sid, s0.surf * L1 + s0.emit);
+                    W.state[sid] = kDone;
+                    continue;
+                }
+            }
+            W.state[sid] = kRay2;
+            W.org[sid] = make_float4(p1.x, p1.y, p1.z, 0.0f);
+            W.dir[sid] = make_float4(d2.x, d2.y, d2.z, __int_as_float(tri1));
         }
-        W.state[sid] = kRay2;
-        W.org[sid] = make_float4(p1.x, p1.y, p1.z, 0.0f);
-        W.dir[sid] = make_float4(d2.x, d2.y, d2.z, __int_as_float(tri1));
     }
 }
 
@@ -1239,6 +1241,14 @@ int launch_frame(sq_device_scene* s, const Frame& F, hipStream_t stream) {
     }
     SQ_HIP(hipGetLastError());
     const int aux_blocks = s->n_cu * (int)(s->opt_aux_blocks_per_cu ? s->opt_aux_blocks_per_cu : 8);
+    // per-sample kernels that run one thread per active pixel: x covers the pixels, y splits a pixel's samples when the
+    // frame has too few pixels to fill the chip (one rank's share of a frame, small frames)
+    auto pp_grid = [&](int kc) {
+        const long long bx = std::max<long long>(1, std::min<long long>((pixels + kBlock - 1) / kBlock, 1 << 20));
+        const long long want_threads = (long long)s->n_cu * 2048 * 2;
+        const long long ks = std::max<long long>(1, std::min<long long>(std::min(kc, 64), (want_threads + pixels - 1) / std::max<long long>(pixels, 1)));
+        return dim3((unsigned)bx, (unsigned)ks);
+    };
     auto launch_trace = [&](const Work& W, int kc, int level, hipStream_t on, bool with_mirror_rays = false) -> int {
         // a launch with few slots (the per-pixel mirror rays) takes small reservations, or only a few waves get any
         const int max_chunk = resident ? kChunkResident : kChunkStreaming;
@@ -1275,14 +1285,14 @@ int launch_frame(sq_device_scene* s, const Frame& F, hipStream_t stream) {
         for (int i = 0; i < n_real; ++i) {
             const int k0 = k0_of(i), kc = kc_of(i);
             SQ_HIP(hipMemsetAsync(W.head[0], 0, 32 * sizeof(int32_t), stream));     // both dequeue cursors
-            hipLaunchKernelGGL(sq_gen_bounce1, dim3(aux_blocks), dim3(kBlock), 0, stream, S, F, W, k0, kc);
+            hipLaunchKernelGGL(sq_gen_bounce1, pp_grid(kc), dim3(kBlock), 0, stream, S, F, W, k0, kc);
             SQ_HIP(hipGetLastError());
             const bool front = mirror_rides && i == 0;
             if (front) hipLaunchKernelGGL(sq_mirror1_gen, dim3(aux_blocks), dim3(kBlock), 0, stream, S, F, W, (long long)W.slot_capacity);
             for (int level = 0; level < 2; ++level) {
                 if (launch_trace(W, kc, level, stream, front && level == 0)) return 1;
                 if (front && level == 0) hipLaunchKernelGGL(sq_mirror1_store, dim3(aux_blocks), dim3(kBlock), 0, stream, W, (long long)W.slot_capacity);
-                if (level == 0) hipLaunchKernelGGL(sq_shade1, dim3(aux_blocks), dim3(kBlock), 0, stream, S, F, W, kc);
+                if (level == 0) hipLaunchKernelGGL(sq_shade1, pp_grid(kc), dim3(kBlock), 0, stream, S, F, W, kc);
                 SQ_HIP(hipGetLastError());
             }
             hipLaunchKernelGGL(sq_accumulate, dim3(aux_blocks), dim3(kBlock), 0, stream, S, F, W, kc, (k0 + kc >= F.samples) ? 1 : 0);
@@ -1315,10 +1325,10 @@ int launch_frame(sq_device_scene* s, const Frame& F, hipStream_t stream) {
             const Work& V = Wt[i & 1];
             const int k0 = k0_of(i), kc = kc_of(i);
             SQ_HIP(hipMemsetAsync(V.head[0], 0, 32 * sizeof(int32_t), on));
-            hipLaunchKernelGGL(sq_gen_bounce1, dim3(aux_blocks), dim3(kBlock), 0, on, S, F, V, k0, kc);
+            hipLaunchKernelGGL(sq_gen_bounce1, pp_grid(kc), dim3(kBlock), 0, on, S, F, V, k0, kc);
             SQ_HIP(hipGetLastError());
             if (launch_trace(V, kc, 0, on)) return 1;
-            hipLaunchKernelGGL(sq_shade1, dim3(aux_blocks), dim3(kBlock), 0, on, S, F, V, kc);
+            hipLaunchKernelGGL(sq_shade1, pp_grid(kc), dim3(kBlock), 0, on, S, F, V, kc);
             SQ_HIP(hipGetLastError());
             if (launch_trace(V, kc, 1, on)) return 1;
             if (i > 0) SQ_HIP(hipStreamWaitEvent(on, eAcc[(size_t)i - 1], 0));
@@ -1340,7 +1350,7 @@ int launch_frame(sq_device_scene* s, const Frame& F, hipStream_t stream) {
     auto gen = [&](int i) -> int {                          // on X
         const Work& V = Wt[i & 1];
         SQ_HIP(hipMemsetAsync(V.head[0], 0, 32 * sizeof(int32_t), X));
-        hipLaunchKernelGGL(sq_gen_bounce1, dim3(aux_blocks), dim3(kBlock), 0, X, S, F, V, k0_of(i), kc_of(i));
+        hipLaunchKernelGGL(sq_gen_bounce1, pp_grid(kc_of(i)), dim3(kBlock), 0, X, S, F, V, k0_of(i), kc_of(i));
         SQ_HIP(hipGetLastError());
         SQ_HIP(hipEventRecord(eG[(size_t)i], X));
         return 0;
@@ -1353,7 +1363,7 @@ int launch_frame(sq_device_scene* s, const Frame& F, hipStream_t stream) {
     };
     auto shade1 = [&](int i) -> int {                       // on X
         SQ_HIP(hipStreamWaitEvent(X, eT1[(size_t)i], 0));
-        hipLaunchKernelGGL(sq_shade1, dim3(aux_blocks), dim3(kBlock), 0, X, S, F, Wt[i & 1], kc_of(i));
+        hipLaunchKernelGGL(sq_shade1, pp_grid(kc_of(i)), dim3(kBlock), 0, X, S, F, Wt[i & 1], kc_of(i));
         SQ_HIP(hipGetLastError());
         SQ_HIP(hipEventRecord(eS1[(size_t)i], X));
         return 0;
