@@ -59,6 +59,13 @@ using LiveT = uint8_t;             // a live slot's index within its chunk
 #endif
 constexpr int kStatSlots = 32;            // sq_get_stats
 constexpr int kPoolWindows = SQ_POOL_KW;   // pooled trace kernel: pair windows a wave works on at a time
+#ifndef SQ_POOL_TPL
+#define SQ_POOL_TPL 2
+#endif
+// Pooled trace kernel: triangles a lane tests per window.  Two for the resident form (one owner lookup and one set of pulls
+// serve two tests: 83.0 -> 80.5 ms on the headline frame, same run); one for the streaming form, whose loads want the
+// registers (the 1M-triangle scene loses 14 % with two).
+constexpr int kPoolTrisResident = SQ_POOL_TPL, kPoolTrisStreaming = 1;
 
 // ----------------------------------------------------------------------------------------------
 // Frame description shared by the kernels
@@ -609,6 +616,80 @@ __global__ void __launch_bounds__(BLOCK) sq_trace_rays(const SceneView S, const 
                 const int2 lf = G.leaf(T.cur);
                 lf_first = lf.x; lf_cnt = lf.y; T.R.tri = -1;
                 T.mode = lf.y > 0 ? M_LEAFQ : M_UNWIND;
+            }
+            if constexpr ((RESIDENT ? kPoolTrisResident : kPoolTrisStreaming) == 2) {
+                // Two triangles per lane and window.  The pool is counted in UNITS of two consecutive triangles of one leaf (a
+                // leaf with an odd number of triangles ends in a half unit), so that one owner lookup and one set of pulls
+                // serve two triangle tests: the pulls are the most expensive part of a window (ds_bpermute, 6 cycles per CU
+                // each), and the lookup's integer VALU work comes next.
+                const int c2 = (T.mode == M_LEAFQ) ? lf_cnt : 0;                // triangles left in this lane's open leaf
+                if (__ballot(c2 > 0) == 0) continue;
+                const int u = (c2 + 1) >> 1;                                    // units
+                const int incl = wave_scan_add(u);
+                const int U = __builtin_amdgcn_readlane(incl, 63);
+                const int start = incl - u;
+                const int tb2 = lf_first - 2 * start;                           // first triangle of unit q = 2 q + tb2
+                const int tri_end = lf_first + c2;                              // one past the leaf's last triangle
+                int nwin = U >> 6;
+                const int rem = U & 63;
+                const bool others = __ballot(T.mode == M_UNWIND || T.mode == M_DESCEND) != 0;
+                if (rem && (!others || carry || rem >= A.flush_min)) ++nwin;
+                stamp(3);
+                for (int w = 0; w < nwin; ++w) {
+                    const int base = w << 6;
+                    const int h = start - base;
+                    if (u > 0 && h < 64 && incl > base) tab[h > 0 ? h : 0] = (uint8_t)lane_tag;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    int own = tab[lane];
+                    tab[lane] = 0;
+                    own = wave_scan_max(own);
+                    const int q = base + lane;
+                    const bool act = q < U;
+                    int tri0 = 2 * q + lane_pull(tb2, own);
+                    const int end_o = lane_pull(tri_end, own);
+                    const f3 po = sq::mk(lane_pull(T.o.x, own), lane_pull(T.o.y, own), lane_pull(T.o.z, own));
+                    const f3 pd = sq::mk(lane_pull(T.d.x, own), lane_pull(T.d.y, own), lane_pull(T.d.z, own));
+                    if (!act) tri0 = 0;                                         // lanes past the last unit test triangle 0 and drop the answer
+                    const bool second = act && tri0 + 1 < end_o;                // a half unit has no second triangle
+                    const int tri1 = second ? tri0 + 1 : tri0;
+                    stamp(4);
+                    f3 v0a, e1a, e2a, v0b, e1b, e2b;
+                    G.get1(tri0, v0a, e1a, e2a);
+                    G.get1(tri1, v0b, e1b, e2b);
+                    float ta, tb_;
+                    const bool hita = moller_trumbore_flat(po, pd, v0a, e1a, e2a, ta) & act;
+                    const bool hitb = moller_trumbore_flat(po, pd, v0b, e1b, e2b, tb_) & second;
+                    stamp(5);
+                    const unsigned long long ma = __ballot(hita), mb = __ballot(hitb);
+                    unsigned long long hm = ma | mb;
+                    if (PROFILE) pl_hit += (int)hita + (int)hitb;
+                    while (hm) {                                                // accepted hits in leaf order: lane by lane, first then second triangle
+                        const int l = __ffsll((long long)hm) - 1;
+                        hm &= hm - 1;
+                        const int so = __builtin_amdgcn_readlane(own, l);
+                        const int stri = __builtin_amdgcn_readlane(tri0, l);
+                        if ((ma >> l) & 1ull) {
+                            const float st = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ta), l));
+                            if (lane_tag == so && (T.R.tri < 0 || dist_gt(T.o, T.d, T.R.t, st, T.safe))) { T.R.t = st; T.R.tri = stri; }
+                        }
+                        if ((mb >> l) & 1ull) {
+                            const float st = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tb_), l));
+                            if (lane_tag == so && (T.R.tri < 0 || dist_gt(T.o, T.d, T.R.t, st, T.safe))) { T.R.t = st; T.R.tri = stri + 1; }
+                        }
+                    }
+                    stamp(6);
+                }
+                const int done = min(U, nwin << 6);                             // units tested
+                if (PROFILE) { pf_leaf += nwin; pf_outer += 2 * done; }
+                if (u > 0) {
+                    if (incl <= done) T.mode = M_UNWIND;                        // the Leaf equation is finished: R is its value
+                    else if (start < done) { lf_first += 2 * (done - start); lf_cnt -= 2 * (done - start); }   // whole units come first: two triangles each
+                }
+                carry = done < U;
+                stamp(7);
+                continue;
             }
             const int c = (T.mode == M_LEAFQ) ? lf_cnt : 0;
             if (__ballot(c > 0) == 0) continue;
