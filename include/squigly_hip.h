@@ -125,9 +125,11 @@ int  sq_set_option(sq_device_scene* s, const char* key, int64_t value);
  *   SQ_OP_UNIT_FLOAT             : a = n uint32 -> out = n floats (randomR (0,1), src/Lib.hs:183-188)
  *   SQ_OP_TFGEN3                 : a = n int64 seeds -> out = 3n uint32 (first three outputs of mkTFGen seed)
  *   SQ_OP_TONEMAP                : a = 3n floats -> out = 3n bytes (src/Lib.hs:93-104)
+ *   SQ_OP_RCP_SWEEP              : a = n uint32 (upper 16 bits of a float) -> out = n uint32: among the 65536 floats x with
+ *                                  those upper bits, how many have the triangle test's short reciprocal != 1.0f / x
  * a, b, out are HOST pointers. */
 enum { SQ_OP_SQRT = 0, SQ_OP_DIV = 1, SQ_OP_SIN = 2, SQ_OP_COS = 3, SQ_OP_ACOS = 4, SQ_OP_ATAN = 5,
-       SQ_OP_UNIT_FLOAT = 6, SQ_OP_TFGEN3 = 7, SQ_OP_TONEMAP = 8 };
+       SQ_OP_UNIT_FLOAT = 6, SQ_OP_TFGEN3 = 7, SQ_OP_TONEMAP = 8, SQ_OP_RCP_SWEEP = 9 };
 int sq_debug_eval(int32_t device, int32_t op, const void* a, const void* b, int64_t n, void* out);
 
 int32_t     sq_device_count(void);

@@ -113,7 +113,7 @@ def lib():
     return L
 
 
-OPS = {"sqrt": 0, "div": 1, "sin": 2, "cos": 3, "acos": 4, "atan": 5, "unit_float": 6, "tfgen3": 7, "tonemap": 8}
+OPS = {"sqrt": 0, "div": 1, "sin": 2, "cos": 3, "acos": 4, "atan": 5, "unit_float": 6, "tfgen3": 7, "tonemap": 8, "rcp_sweep": 9}
 
 
 def debug_eval(op, a, b=None, device=0):
@@ -125,6 +125,8 @@ def debug_eval(op, a, b=None, device=0):
         a = np.ascontiguousarray(a, np.float32).reshape(-1, 3); n = len(a); out = np.empty((n, 3), np.uint8)
     elif op == "unit_float":
         a = np.ascontiguousarray(a, np.uint32); n = a.size; out = np.empty(n, np.float32)
+    elif op == "rcp_sweep":
+        a = np.ascontiguousarray(a, np.uint32); n = a.size; out = np.empty(n, np.uint32)
     else:
         a = np.ascontiguousarray(a, np.float32); n = a.size; out = np.empty(n, np.float32)
     if b is not None:

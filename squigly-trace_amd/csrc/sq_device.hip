@@ -426,7 +426,7 @@ __host__ __device__ inline TraceLds trace_lds_layout(int n_lds, bool resident, i
     L.verts = off; off += resident ? al((uint32_t)n_verts * 16u) : 0u;     // first: a vertex's LDS address is its byte offset (ResidentTris)
     L.quads = off; off += al((uint32_t)n_lds * (resident ? 32u : 48u));   // resident: 2 quads per branch; streaming: 3
     L.refs = off;  off += resident ? al((uint32_t)n_lds * 8u) : 0u;
-    L.trix = off;  off += resident ? al((uint32_t)n_tris * 8u) : 0u;
+    L.trix = off;  off += resident ? al((uint32_t)(n_tris + ResidentTris::kRunPad) * 8u) : 0u;  // + zero records: get_run may read past the last triangle
     L.live = off;  off += al((uint32_t)(block / 64) * (uint32_t)(resident ? kChunkResident : kChunkStreaming) * (uint32_t)sizeof(LiveT));
     L.tab = off;   off += pool ? al((uint32_t)block * kPoolWindows) : 0u;   // pooled form: one byte per lane and window in flight
     L.stack = off; off += al((uint32_t)block * (uint32_t)stack_cap * (uint32_t)stack_elem);
@@ -457,6 +457,7 @@ __device__ __forceinline__ void stage_resident_scene(const SceneView& S, int n_b
         const ushort4 t = S.trix[i];
         lt[i] = v4us{ (unsigned short)(t.x * 16u), (unsigned short)(t.y * 16u), (unsigned short)(t.z * 16u), t.w };
     }
+    if (threadIdx.x < ResidentTris::kRunPad) lt[S.n_tris + threadIdx.x] = v4us{ 0, 0, 0, 0 };
     N = ResidentNodes{ lquads, lrefs };
     G = ResidentTris{ lt };
     if ((uintptr_t)lv != 0) __builtin_trap();                              // the kernels that use this have no static LDS: dynamic LDS starts at address 0
@@ -617,18 +618,19 @@ __global__ void __launch_bounds__(BLOCK) sq_trace_rays(const SceneView S, const 
                 lf_first = lf.x; lf_cnt = lf.y; T.R.tri = -1;
                 T.mode = lf.y > 0 ? M_LEAFQ : M_UNWIND;
             }
-            if constexpr ((RESIDENT ? kPoolTrisResident : kPoolTrisStreaming) == 2) {
-                // Two triangles per lane and window.  The pool is counted in UNITS of two consecutive triangles of one leaf (a
-                // leaf with an odd number of triangles ends in a half unit), so that one owner lookup and one set of pulls
-                // serve two triangle tests: the pulls are the most expensive part of a window (ds_bpermute, 6 cycles per CU
-                // each), and the lookup's integer VALU work comes next.
+            if constexpr ((RESIDENT ? kPoolTrisResident : kPoolTrisStreaming) >= 2) {
+                // NT triangles per lane and window.  The pool is counted in UNITS of NT consecutive triangles of one leaf (the
+                // last unit of a leaf may be part-filled), so that one owner lookup and one set of pulls serve NT triangle
+                // tests: the pulls are the most expensive part of a window (ds_bpermute, 6 cycles per CU each), and the
+                // lookup's integer VALU work comes next.
+                constexpr int NT = RESIDENT ? kPoolTrisResident : kPoolTrisStreaming;
                 const int c2 = (T.mode == M_LEAFQ) ? lf_cnt : 0;                // triangles left in this lane's open leaf
                 if (__ballot(c2 > 0) == 0) continue;
-                const int u = (c2 + 1) >> 1;                                    // units
+                const int u = (c2 + NT - 1) / NT;                               // units
                 const int incl = wave_scan_add(u);
                 const int U = __builtin_amdgcn_readlane(incl, 63);
                 const int start = incl - u;
-                const int tb2 = lf_first - 2 * start;                           // first triangle of unit q = 2 q + tb2
+                const int tb2 = lf_first - NT * start;                          // first triangle of unit q = NT q + tb2
                 const int tri_end = lf_first + c2;                              // one past the leaf's last triangle
                 int nwin = U >> 6;
                 const int rem = U & 63;
@@ -647,45 +649,41 @@ __global__ void __launch_bounds__(BLOCK) sq_trace_rays(const SceneView S, const 
                     own = wave_scan_max(own);
                     const int q = base + lane;
                     const bool act = q < U;
-                    int tri0 = 2 * q + lane_pull(tb2, own);
+                    int tri0 = NT * q + lane_pull(tb2, own);
                     const int end_o = lane_pull(tri_end, own);
                     const f3 po = sq::mk(lane_pull(T.o.x, own), lane_pull(T.o.y, own), lane_pull(T.o.z, own));
                     const f3 pd = sq::mk(lane_pull(T.d.x, own), lane_pull(T.d.y, own), lane_pull(T.d.z, own));
                     if (!act) tri0 = 0;                                         // lanes past the last unit test triangle 0 and drop the answer
-                    const bool second = act && tri0 + 1 < end_o;                // a half unit has no second triangle
-                    const int tri1 = second ? tri0 + 1 : tri0;
                     stamp(4);
-                    f3 v0a, e1a, e2a, v0b, e1b, e2b;
-                    G.get1(tri0, v0a, e1a, e2a);
-                    G.get1(tri1, v0b, e1b, e2b);
-                    float ta, tb_;
-                    const bool hita = moller_trumbore_flat(po, pd, v0a, e1a, e2a, ta) & act;
-                    const bool hitb = moller_trumbore_flat(po, pd, v0b, e1b, e2b, tb_) & second;
+                    f3 v0[NT], e1[NT], e2[NT];
+                    G.template get_run<NT>(tri0, v0, e1, e2);                   // a part-filled unit tests the records after it and drops the answers
+                    float tt[NT]; bool hit[NT]; unsigned long long hmk[NT], hm = 0;
+#pragma unroll
+                    for (int k = 0; k < NT; ++k) {
+                        const bool valid = act && (k == 0 || tri0 + k < end_o);
+                        hit[k] = moller_trumbore_flat(po, pd, v0[k], e1[k], e2[k], tt[k]) & valid;
+                    }
                     stamp(5);
-                    const unsigned long long ma = __ballot(hita), mb = __ballot(hitb);
-                    unsigned long long hm = ma | mb;
-                    if (PROFILE) pl_hit += (int)hita + (int)hitb;
-                    while (hm) {                                                // accepted hits in leaf order: lane by lane, first then second triangle
+#pragma unroll
+                    for (int k = 0; k < NT; ++k) { hmk[k] = __ballot(hit[k]); hm |= hmk[k]; if (PROFILE) pl_hit += (int)hit[k]; }
+                    while (hm) {                                                // accepted hits in leaf order: lane by lane, a lane's triangles in turn
                         const int l = __ffsll((long long)hm) - 1;
                         hm &= hm - 1;
                         const int so = __builtin_amdgcn_readlane(own, l);
                         const int stri = __builtin_amdgcn_readlane(tri0, l);
-                        if ((ma >> l) & 1ull) {
-                            const float st = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ta), l));
-                            if (lane_tag == so && (T.R.tri < 0 || dist_gt(T.o, T.d, T.R.t, st, T.safe))) { T.R.t = st; T.R.tri = stri; }
-                        }
-                        if ((mb >> l) & 1ull) {
-                            const float st = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tb_), l));
-                            if (lane_tag == so && (T.R.tri < 0 || dist_gt(T.o, T.d, T.R.t, st, T.safe))) { T.R.t = st; T.R.tri = stri + 1; }
+#pragma unroll
+                        for (int k = 0; k < NT; ++k) if ((hmk[k] >> l) & 1ull) {
+                            const float st = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tt[k]), l));
+                            if (lane_tag == so && (T.R.tri < 0 || dist_gt(T.o, T.d, T.R.t, st, T.safe))) { T.R.t = st; T.R.tri = stri + k; }
                         }
                     }
                     stamp(6);
                 }
                 const int done = min(U, nwin << 6);                             // units tested
-                if (PROFILE) { pf_leaf += nwin; pf_outer += 2 * done; }
+                if (PROFILE) { pf_leaf += nwin; pf_outer += NT * done; }
                 if (u > 0) {
                     if (incl <= done) T.mode = M_UNWIND;                        // the Leaf equation is finished: R is its value
-                    else if (start < done) { lf_first += 2 * (done - start); lf_cnt -= 2 * (done - start); }   // whole units come first: two triangles each
+                    else if (start < done) { lf_first += NT * (done - start); lf_cnt -= NT * (done - start); }   // whole units come first
                 }
                 carry = done < U;
                 stamp(7);
@@ -837,6 +835,14 @@ __global__ void sq_debug_kernel(int op, const void* a, const void* b, long long 
             uint32_t* o = (uint32_t*)out + 3 * i; o[0] = n0; o[1] = n1; o[2] = n2; break;
         }
         case SQ_OP_TONEMAP: tonemap(sq::mk(fa[3 * i], fa[3 * i + 1], fa[3 * i + 2]), (uint8_t*)out + 3 * i); break;
+        case SQ_OP_RCP_SWEEP: {                                            // all 65536 floats whose upper 16 bits are a[i]
+            const uint32_t hi = ((const uint32_t*)a)[i] << 16; uint32_t bad = 0;
+            for (uint32_t lo = 0; lo < 65536u; ++lo) {
+                const float x = __uint_as_float(hi | lo);
+                bad += __float_as_uint(rcp_midrange(x)) != __float_as_uint(1.0f / x);
+            }
+            ((uint32_t*)out)[i] = bad; break;
+        }
         default: break;
     }
 }
@@ -1656,7 +1662,7 @@ extern "C" int sq_render_f32(const sq_scene* scene, const sq_camera* cam, int32_
 }
 
 extern "C" int sq_debug_eval(int32_t device, int32_t op, const void* a, const void* b, int64_t n, void* out) {
-    if (!a || !out || n < 0 || op < 0 || op > SQ_OP_TONEMAP) return sq_set_error("bad argument");
+    if (!a || !out || n < 0 || op < 0 || op > SQ_OP_RCP_SWEEP) return sq_set_error("bad argument");
     if (op == SQ_OP_DIV && !b) return sq_set_error("SQ_OP_DIV needs b");
     if (n == 0) return 0;
     int ndev = 0;

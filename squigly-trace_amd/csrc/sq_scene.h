@@ -100,6 +100,9 @@ __device__ __forceinline__ bool finite3(f3 v) {
     return __builtin_isfinite(v.x) && __builtin_isfinite(v.y) && __builtin_isfinite(v.z);
 }
 
+#ifndef SQ_FAST_RCP
+#define SQ_FAST_RCP 1
+#endif
 // mollerTrumbore (src/Geometry.hs:117-142) on (v0, e1, e2)
 __device__ __forceinline__ bool moller_trumbore(f3 o, f3 d, f3 v0, f3 e1, f3 e2, float& t_out) {
     const float eps = 0.0001f;
@@ -118,6 +121,19 @@ __device__ __forceinline__ bool moller_trumbore(f3 o, f3 d, f3 v0, f3 e1, f3 e2,
     t_out = t;
     return true;
 }
+// 1/a for the determinant of the pooled triangle test, where the full IEEE division sequence (11 VALU instructions) is a
+// seventh of the arithmetic: v_rcp_f32 (1 ulp) and two Newton steps in FMA form.  The second step is Markstein's final
+// correction, which rounds correctly when its input is within an ulp; that this holds for EVERY float with
+// 2^-14 <= |a| <= 2^100 (all intermediates normal there) is not argued but checked: SQ_OP_RCP_SWEEP compares it with
+// 1.0f / a for all 1.9e9 of them (tests/test_gpu_parity.py).  Outside that range the caller must divide.
+constexpr float kRcpMidLo = 0x1p-14f, kRcpMidHi = 0x1p100f;
+__device__ __forceinline__ float rcp_midrange(float a) {
+    float r = __builtin_amdgcn_rcpf(a);
+    float e = __builtin_fmaf(-a, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);
+    e = __builtin_fmaf(-a, r, 1.0f);
+    return __builtin_fmaf(e, r, r);
+}
 // The same function without early exits: every value is produced by the same expression as above (a zero `a` makes
 // f infinite and the later values NaN or infinite, which the conjunction then rejects exactly as the first guard does).
 // For a full wave of unrelated (ray, triangle) pairs some lane nearly always reaches the last guard, so the exits
@@ -126,7 +142,14 @@ __device__ __forceinline__ bool moller_trumbore_flat(f3 o, f3 d, f3 v0, f3 e1, f
     const float eps = 0.0001f;
     const f3 h = sq::cross(d, e2);
     const float a = sq::dot(e1, h);
+#if SQ_FAST_RCP
+    // |a| < eps fails g1 whatever f is (eps > kRcpMidLo), so only a huge, infinite or NaN determinant needs the division;
+    // the test is wave-uniform so that the common case pays no divergence
+    float f;
+    if (__ballot(!(__builtin_fabsf(a) <= kRcpMidHi))) f = 1.0f / a; else f = rcp_midrange(a);
+#else
     const float f = 1.0f / a;
+#endif
     const f3 s = o - v0;
     const float u = f * sq::dot(s, h);
     const f3 q = sq::cross(s, e1);
@@ -358,6 +381,23 @@ struct ResidentTris {           // whole scene resident in LDS: 16-bit indexed t
         v0 = sq::mk(a.x, a.y, a.z);
         e1 = sq::mk(b.x, b.y, b.z) - v0;
         e2 = sq::mk(c.x, c.y, c.z) - v0;
+    }
+    // N consecutive records: 16-byte reads of two records each (ds_read2_b64: the records are 8-byte aligned), offsets unpacked
+    // by VALU -- a third of the LDS instructions of 16-bit reads.  kRunPad zero records follow the last triangle, so a run
+    // that starts at any triangle is readable.
+    static constexpr int kRunPad = 3;
+    template <int N>
+    __device__ __forceinline__ void get_run(int i, f3* v0, f3* e1, f3* e2) const {
+        typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+        const SQ_LDS v2u* r = reinterpret_cast<const SQ_LDS v2u*>(trix + i);
+        v2u rec[N];
+#pragma unroll
+        for (int k = 0; k < N; ++k) rec[k] = r[k];
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const v4f a = vertex(rec[k].x & 0xffffu), b = vertex(rec[k].x >> 16), c = vertex(rec[k].y & 0xffffu);
+            v0[k] = sq::mk(a.x, a.y, a.z); e1[k] = sq::mk(b.x, b.y, b.z) - v0[k]; e2[k] = sq::mk(c.x, c.y, c.z) - v0[k];
+        }
     }
     __device__ __forceinline__ v4us index(int i) const { return trix[i]; }
     __device__ __forceinline__ void get_indexed(v4us r, f3& v0, f3& e1, f3& e2) const {

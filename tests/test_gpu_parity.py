@@ -262,6 +262,20 @@ def test_device_primitives_bit_exact(sqt, O):
     assert np.array_equal(got, want)
 
 
+def test_short_reciprocal_is_the_ieee_quotient_on_its_whole_range(sqt):
+    """The pooled triangle test replaces 1 / det by v_rcp_f32 + two FMA Newton steps where 2^-14 <= |det| <= 2^100
+    (sq_scene.h rcp_midrange; smaller determinants are rejected by the test's first guard, larger ones take the division).
+    Exhaustive: every float of that range, both signs (1.9e9 values), against the device's IEEE division, which
+    test_device_primitives_bit_exact ties to numpy's."""
+    lo, hi = 0x3880, 0x7180                      # upper halves of 2^-14 and 2^100
+    blocks = np.arange(lo, hi + 1, dtype=np.uint32)
+    blocks = np.concatenate([blocks, blocks | 0x8000]).astype(np.uint32)
+    bad = sqt.debug_eval("rcp_sweep", blocks)
+    assert int(bad.sum()) == 0, [(hex(int(b)), int(c)) for b, c in zip(blocks[bad > 0][:8], bad[bad > 0][:8])]
+    # outside the range the short form is NOT exact (which is why the kernel checks): denormal results lose bits
+    assert int(sqt.debug_eval("rcp_sweep", np.array([0x7e80], np.uint32)).sum()) > 0
+
+
 def test_axis_aligned_rays_take_the_exact_slab_path(sqt, O):
     """A camera with zero Euler angles shoots dir = (1, xoffs, yoffs): the centre column has d.y == 0 and the
     centre row d.z == 0, so 1/d is infinite, `(bound - o) * df` can be 0 * inf = NaN, and the traversal must
