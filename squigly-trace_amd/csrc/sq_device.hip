@@ -65,7 +65,13 @@ constexpr int kPoolWindows = SQ_POOL_KW;   // pooled trace kernel: pair windows 
 // Pooled trace kernel: triangles a lane tests per window.  Two for the resident form (one owner lookup and one set of pulls
 // serve two tests: 83.0 -> 80.5 ms on the headline frame, same run); one for the streaming form, whose loads want the
 // registers (the 1M-triangle scene loses 14 % with two).
-constexpr int kPoolTrisResident = SQ_POOL_TPL, kPoolTrisStreaming = 1;
+#ifndef SQ_STACK_AHEAD
+#define SQ_STACK_AHEAD 1
+#endif
+#ifndef SQ_POOL_TPL_STREAM
+#define SQ_POOL_TPL_STREAM 2
+#endif
+constexpr int kPoolTrisResident = SQ_POOL_TPL, kPoolTrisStreaming = SQ_POOL_TPL_STREAM;
 
 // ----------------------------------------------------------------------------------------------
 // Frame description shared by the kernels
@@ -594,11 +600,13 @@ __global__ void __launch_bounds__(BLOCK) sq_trace_rays(const SceneView S, const 
         bool carry = false;                 // wave-uniform: the previous iteration left queued pairs untested
         unsigned int pl_hit = 0, pl_hslow = 0;
         TravProf prof{};
+        uint32_t pre_e = 0; BranchTail pre_B{};   // SQ_STACK_AHEAD: the lane's top frame and that branch's tail, read ahead
         // PROFILE: wave time per section of the loop (s_memtime ticks = shader cycles; the stamps themselves cost ~10 %)
         unsigned long long tsec[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, tlast = PROFILE ? __builtin_amdgcn_s_memtime() : 0;
         auto stamp = [&](int sec) { if (PROFILE) { const unsigned long long now = __builtin_amdgcn_s_memtime(); tsec[sec] += now - tlast; tlast = now; } };
         for (;;) {
             if (PROFILE) ++pf_adv;
+            if constexpr (RESIDENT && SQ_STACK_AHEAD) pre_B = N.tail((pre_e & StackTraits<StackT>::flag) ? 0u : pre_e);
             const bool idle = (T.mode == M_DONE);
             if (idle && my_ray >= 0) { A.hits[my_ray] = make_int2(__float_as_int(T.R.t), T.R.tri); my_ray = -1; }
             const unsigned long long m = __ballot(idle);
@@ -608,10 +616,18 @@ __global__ void __launch_bounds__(BLOCK) sq_trace_rays(const SceneView S, const 
             }
             stamp(0);
             if (PROFILE) pl_unw += (T.mode == M_UNWIND);
-            if (T.mode == M_UNWIND) trav_unwind(T, N, G, stk, BLOCK, PROFILE ? &prof : nullptr);
+            if constexpr (RESIDENT && SQ_STACK_AHEAD) {
+                // The frame a return pops and the branch it names were requested an iteration ago (below, after the branch step):
+                // a return's two dependent LDS round trips -- stack word, then that branch's planes and children -- are off its path.
+                if (T.mode == M_UNWIND) {
+                    if (T.sp == 0) T.mode = M_DONE;
+                    else { --T.sp; trav_unwind_frame(T, N, G, stk, BLOCK, pre_e, &pre_B, PROFILE ? &prof : nullptr); }
+                }
+            } else if (T.mode == M_UNWIND) trav_unwind(T, N, G, stk, BLOCK, PROFILE ? &prof : nullptr);
             stamp(1);
             if (PROFILE) pl_desc += (T.mode == M_DESCEND);
             if (T.mode == M_DESCEND) trav_descend(T, N, stk, BLOCK);
+            if constexpr (RESIDENT && SQ_STACK_AHEAD) pre_e = stk[(T.sp > 0 ? T.sp - 1 : 0) * BLOCK];   // every lane: the read costs the wave the same
             stamp(2);
             if (T.mode == M_LEAF) {                                         // open the leaf (src/BIH.hs:105): Nothing so far
                 const int2 lf = G.leaf(T.cur);
@@ -967,6 +983,7 @@ extern "C" int sq_scene_upload(const sq_scene* sc, int32_t device, sq_device_sce
         for (int c = 0; c < 3; ++c) { d.v0[c] = t.v0[c]; d.e1[c] = t.v1[c] - t.v0[c]; d.e2[c] = t.v2[c] - t.v0[c]; }
         tri_mat[(size_t)i] = t.mat;
     }
+    tr.resize((size_t)sc->n_tris + GlobalTris::kRunPad);                   // zero triangles: get_run may read past the last one
     std::vector<DevSurf> sf((size_t)sc->n_tris);
     std::vector<DevMat> mt((size_t)sc->n_mats);
     bool nonneg = true;

@@ -360,6 +360,9 @@ struct GlobalTris {
         }
     }
     __device__ __forceinline__ void get1(int i, f3& v0, f3& e1, f3& e2) const { get_n<1>(i, &v0, &e1, &e2); }   // two 16-byte loads + one dword
+    static constexpr int kRunPad = 3;            // zero triangles after the last one (upload), so a run may start at any triangle
+    template <int N>
+    __device__ __forceinline__ void get_run(int i, f3* v0, f3* e1, f3* e2) const { get_n<N>(i, v0, e1, e2); }
     __device__ __forceinline__ int2 leaf(uint32_t ref) const {
         if (packed) return make_int2((int)(ref & 0xFFFFFFu), (int)((ref >> 24) & 31u));   // saves a dependent load per leaf visit
         return leaves[ref & ~kLeafBit];
@@ -567,12 +570,10 @@ __device__ __forceinline__ void trav_leaf(Trav& T, const TriSrc& G) {
 }
 
 // Return to the caller of the call that just produced R: pop one frame.  Pre: mode == M_UNWIND.
+// `e` is the popped frame; `pre`, when given, is the tail of branch e read ahead of time (FAR frames only).
 template <typename NodeSrc, typename TriSrc, typename StackT>
-__device__ __forceinline__ void trav_unwind(Trav& T, const NodeSrc& N, const TriSrc& G, SQ_LDS StackT* stk, int stride, TravProf* prof = nullptr) {
+__device__ __forceinline__ void trav_unwind_frame(Trav& T, const NodeSrc& N, const TriSrc& G, SQ_LDS StackT* stk, int stride, uint32_t e, const BranchTail* pre, TravProf* prof = nullptr) {
     constexpr uint32_t flag = StackTraits<StackT>::flag;
-    if (T.sp == 0) { T.mode = M_DONE; return; }
-    --T.sp;
-    const uint32_t e = stk[T.sp * stride];
     if (e & flag) {                                                     // minimumByMay over [near, far] (src/BIH.hs:115,120)
         const int32_t ntri = (int32_t)(e & ~flag);
         float nt = T.ct;
@@ -593,7 +594,7 @@ __device__ __forceinline__ void trav_unwind(Trav& T, const NodeSrc& N, const Tri
         const BranchData D = N.load(e);                                 // this branch's own box again; the far child's follows below
         T.blo = sq::mk(D.q0.x, D.q0.y, D.q0.z); T.bhi = sq::mk(D.q1.x, D.q1.y, D.q1.z);
         B = BranchTail{ D.q0.w, D.q1.w, D.axis, D.left, D.right };
-    } else B = N.tail(e);
+    } else B = pre ? *pre : N.tail(e);
     const int ax = B.axis;
     const bool l2r = sq::axis_of(T.d, ax) > 0;
     if (T.R.tri >= 0) {
@@ -609,6 +610,13 @@ __device__ __forceinline__ void trav_unwind(Trav& T, const NodeSrc& N, const Tri
         else     { if (ax == 0) T.bhi.x = B.lmax; else if (ax == 1) T.bhi.y = B.lmax; else T.bhi.z = B.lmax; }
     }
     T.mode = (T.cur & kLeafBit) ? M_LEAF : M_DESCEND;
+}
+
+template <typename NodeSrc, typename TriSrc, typename StackT>
+__device__ __forceinline__ void trav_unwind(Trav& T, const NodeSrc& N, const TriSrc& G, SQ_LDS StackT* stk, int stride, TravProf* prof = nullptr) {
+    if (T.sp == 0) { T.mode = M_DONE; return; }
+    --T.sp;
+    trav_unwind_frame(T, N, G, stk, stride, (uint32_t)stk[T.sp * stride], nullptr, prof);
 }
 
 // Whole query, one ray per lane (used where rays of a wave are coherent: primary and shadow rays).
