@@ -283,6 +283,11 @@ def main():
                              "frac": round(achieved / VALU_PEAK_TLANEOPS, 4),
                              "valu_issue_frac": round(issue, 4), "valu_lane_utilisation": round(lane_util, 4),
                              "valu_wave_instructions_per_launch": int(insts / launches_per_step),
+                             # the other co-limiting unit: the CU's LDS (scene, stacks and the ds_bpermute ray pulls all go
+                             # through it).  array_busy = SQ_LDS_IDX_ACTIVE / (256 CUs x cycles of the trace launches).
+                             "lds": {"array_busy_frac": round(pmc["SQ_LDS_IDX_ACTIVE"] / (N_SIMD / 4 * CLOCK_HZ * trace_s_per_step), 4),
+                                     "bank_conflict_share": round(pmc["SQ_LDS_BANK_CONFLICT"] / pmc["SQ_LDS_IDX_ACTIVE"], 4),
+                                     "instructions_per_launch": int(pmc["SQ_INSTS_LDS"] / launches_per_step)},
                              "traffic": int(traffic),
                              "hbm": {"achieved": round(traffic / (kern_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                      "frac": round(traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},

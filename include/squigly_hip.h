@@ -105,6 +105,9 @@ int  sq_get_stats(sq_device_scene* s, uint64_t* out, int32_t n, int32_t reset);
  *   "refill_min"         pooled kernel: idle lanes a wave collects before it fetches new rays (default 12)
  *   "flush_min"          pooled kernel: a trailing part-filled window of pairs runs at once from this many pairs on,
  *                        otherwise it waits one iteration for more (default 40)
+ *   "pixel_major"        order in which a trace launch takes its queue: 0 = slot order (neighbouring pixels, one sample each),
+ *                        1 = all samples of a pixel in a row (a wave's rays start at one surface point), -1 = choose (default:
+ *                        1 when the triangles exceed the 4 MB L2s, else 0)
  *   "primary_resident"   1 = with a resident scene the primary rays are traced out of LDS too (default), 0 = from L2
  *   "guided"             1 = queue reservations shrink towards the end of a launch (default), 0 = fixed size
  *   "straggler_lanes"    pool = 0: lanes still traversing when a wave turns to its leaves (default 8)

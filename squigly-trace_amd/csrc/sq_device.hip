@@ -65,9 +65,6 @@ constexpr int kPoolWindows = SQ_POOL_KW;   // pooled trace kernel: pair windows 
 // Pooled trace kernel: triangles a lane tests per window.  Two for the resident form (one owner lookup and one set of pulls
 // serve two tests: 83.0 -> 80.5 ms on the headline frame, same run); one for the streaming form, whose loads want the
 // registers (the 1M-triangle scene loses 14 % with two).
-#ifndef SQ_STACK_AHEAD
-#define SQ_STACK_AHEAD 1
-#endif
 #ifndef SQ_POOL_TPL_STREAM
 #define SQ_POOL_TPL_STREAM 2
 #endif
@@ -246,7 +243,11 @@ __global__ void __launch_bounds__(kBlock) sq_gen_bounce1(const SceneView S, cons
                 continue;
             }
             uint32_t n0, n1, n2;
+#ifdef SQ_DIAG_COHERENT   // timing experiment only (WRONG image): every pixel draws the same numbers, so neighbouring rays are parallel
+            sq::tfgen3((long long)(k_base + kl), n0, n1, n2);
+#else
             sq::tfgen3(rix + (k_base + kl), n0, n1, n2);                // mkTFGen (rix + k), src/Lib.hs:86
+#endif
             W.rng12[sid] = make_uint2(n1, n2);
             if (!scatters(P.s0, n0)) {                                  // mirror: traced once per pixel (sq_mirror1_*)
                 W.state[sid] = kMirror;
@@ -417,6 +418,8 @@ struct TraceArgs {
                                  //   launch does not end with a few waves still working through a full reservation
     int32_t refill_min;          // pooled form: idle lanes a wave collects before it fetches new rays for them
     int32_t flush_min;           // pooled form: a trailing part-filled window of the pair pool is run at once from this many pairs on
+    int32_t pixel_major;         // queue ORDER: 0 = slot order (sample-major: neighbouring pixels, one sample each), 1 = all samples
+                                 //   of a pixel in a row, so that a wave's rays start from one surface point (slots stay where they are)
     unsigned long long* stats;   // [0] rays traced; PROFILE builds: [1] advance iterations (waves), [2] lanes unwinding,
                                  // [3] lanes descending, [4] leaf iterations (waves), [5] lanes testing a triangle,
                                  // [6] outer iterations (waves), [7] refill executions (waves), [8] lanes refilled
@@ -454,8 +457,8 @@ __device__ __forceinline__ void stage_resident_scene(const SceneView& S, int n_b
     SQ_LDS v4us* lt = to_lds<v4us>(lds + L.trix);
     for (int i = threadIdx.x; i < n_branches; i += BLOCK) {
         const uint32_t* r = S.rbranch + 10 * (size_t)i;
-        lquads[2 * i] = v4f{ __uint_as_float(r[0]), __uint_as_float(r[1]), __uint_as_float(r[2]), __uint_as_float(r[3]) };
-        lquads[2 * i + 1] = v4f{ __uint_as_float(r[4]), __uint_as_float(r[5]), __uint_as_float(r[6]), __uint_as_float(r[7]) };
+        lquads[i] = v4f{ __uint_as_float(r[0]), __uint_as_float(r[1]), __uint_as_float(r[2]), __uint_as_float(r[3]) };
+        lquads[n_branches + i] = v4f{ __uint_as_float(r[4]), __uint_as_float(r[5]), __uint_as_float(r[6]), __uint_as_float(r[7]) };
         lrefs[i] = v2i{ (int)r[8], (int)r[9] };
     }
     for (int i = threadIdx.x; i < S.n_verts; i += BLOCK) { const float4 v = S.verts4[i]; lv[i] = v4f{ v.x, v.y, v.z, v.w }; }
@@ -464,7 +467,7 @@ __device__ __forceinline__ void stage_resident_scene(const SceneView& S, int n_b
         lt[i] = v4us{ (unsigned short)(t.x * 16u), (unsigned short)(t.y * 16u), (unsigned short)(t.z * 16u), t.w };
     }
     if (threadIdx.x < ResidentTris::kRunPad) lt[S.n_tris + threadIdx.x] = v4us{ 0, 0, 0, 0 };
-    N = ResidentNodes{ lquads, lrefs };
+    N = ResidentNodes{ lquads, lquads + n_branches, lrefs };
     G = ResidentTris{ lt };
     if ((uintptr_t)lv != 0) __builtin_trap();                              // the kernels that use this have no static LDS: dynamic LDS starts at address 0
 }
@@ -523,7 +526,13 @@ __global__ void __launch_bounds__(BLOCK) sq_trace_rays(const SceneView S, const 
     __syncthreads();
     const long long n_front = A.front ? (long long)(*A.n_active) : 0;
     const long long n = (long long)(*A.n_active) * A.k_count + n_front;          // queue positions; slot_of() maps them to slots
-    auto slot_of = [&](long long q) { return q < n_front ? A.front_base + q : q - n_front; };
+    const unsigned n_pix = (unsigned)(*A.n_active), kq = (unsigned)A.k_count;
+    auto slot_of = [&](long long q) -> long long {
+        if (q < n_front) return A.front_base + q;
+        if (!A.pixel_major) return q - n_front;
+        const unsigned r = (unsigned)(q - n_front), a = r / kq, k = r - a * kq;   // slot = sample * pixels + pixel (Work)
+        return (long long)k * n_pix + a;
+    };
     const int lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     long long chunk_base = 0;               // wave-uniform
@@ -600,13 +609,11 @@ __global__ void __launch_bounds__(BLOCK) sq_trace_rays(const SceneView S, const 
         bool carry = false;                 // wave-uniform: the previous iteration left queued pairs untested
         unsigned int pl_hit = 0, pl_hslow = 0;
         TravProf prof{};
-        uint32_t pre_e = 0; BranchTail pre_B{};   // SQ_STACK_AHEAD: the lane's top frame and that branch's tail, read ahead
         // PROFILE: wave time per section of the loop (s_memtime ticks = shader cycles; the stamps themselves cost ~10 %)
         unsigned long long tsec[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, tlast = PROFILE ? __builtin_amdgcn_s_memtime() : 0;
         auto stamp = [&](int sec) { if (PROFILE) { const unsigned long long now = __builtin_amdgcn_s_memtime(); tsec[sec] += now - tlast; tlast = now; } };
         for (;;) {
             if (PROFILE) ++pf_adv;
-            if constexpr (RESIDENT && SQ_STACK_AHEAD) pre_B = N.tail((pre_e & StackTraits<StackT>::flag) ? 0u : pre_e);
             const bool idle = (T.mode == M_DONE);
             if (idle && my_ray >= 0) { A.hits[my_ray] = make_int2(__float_as_int(T.R.t), T.R.tri); my_ray = -1; }
             const unsigned long long m = __ballot(idle);
@@ -616,18 +623,10 @@ __global__ void __launch_bounds__(BLOCK) sq_trace_rays(const SceneView S, const 
             }
             stamp(0);
             if (PROFILE) pl_unw += (T.mode == M_UNWIND);
-            if constexpr (RESIDENT && SQ_STACK_AHEAD) {
-                // The frame a return pops and the branch it names were requested an iteration ago (below, after the branch step):
-                // a return's two dependent LDS round trips -- stack word, then that branch's planes and children -- are off its path.
-                if (T.mode == M_UNWIND) {
-                    if (T.sp == 0) T.mode = M_DONE;
-                    else { --T.sp; trav_unwind_frame(T, N, G, stk, BLOCK, pre_e, &pre_B, PROFILE ? &prof : nullptr); }
-                }
-            } else if (T.mode == M_UNWIND) trav_unwind(T, N, G, stk, BLOCK, PROFILE ? &prof : nullptr);
+            if (T.mode == M_UNWIND) trav_unwind(T, N, G, stk, BLOCK, PROFILE ? &prof : nullptr);
             stamp(1);
             if (PROFILE) pl_desc += (T.mode == M_DESCEND);
             if (T.mode == M_DESCEND) trav_descend(T, N, stk, BLOCK);
-            if constexpr (RESIDENT && SQ_STACK_AHEAD) pre_e = stk[(T.sp > 0 ? T.sp - 1 : 0) * BLOCK];   // every lane: the read costs the wave the same
             stamp(2);
             if (T.mode == M_LEAF) {                                         // open the leaf (src/BIH.hs:105): Nothing so far
                 const int2 lf = G.leaf(T.cur);
@@ -882,7 +881,7 @@ struct sq_device_scene {
     // second stream of the overlapped schedule (launch_frame) and its event pool
     hipStream_t aux = nullptr; std::vector<hipEvent_t> events;
     int64_t opt_overlap = 0, opt_aux_blocks_per_cu = 0;
-    int64_t opt_pool = 1, opt_refill_min = 12, opt_flush_min = 40, opt_guided = 1, opt_primary_resident = 1;
+    int64_t opt_pool = 1, opt_refill_min = 12, opt_flush_min = 40, opt_guided = 1, opt_primary_resident = 1, opt_pixel_major = -1;
 };
 
 namespace {
@@ -1358,12 +1357,15 @@ int launch_frame(sq_device_scene* s, const Frame& F, hipStream_t stream) {
         const int max_chunk = resident ? kChunkResident : kChunkStreaming;
         const int64_t per_wave = pixels * (int64_t)kc / std::max(1, trace_blocks * (trace_threads / 64));
         const int chunk = (int)std::min<int64_t>(max_chunk, std::max<int64_t>(64, (per_wave / 8) / 64 * 64));
+        // queue order: a pixel's samples in a row pays once the triangles no longer fit the L2s (rays that start at one point
+        // share their first leaves: 1M-triangle scene +2.5 %), and costs 1-7 % below that (strided queue reads)
+        const bool pixel_major = s->opt_pixel_major < 0 ? (!resident && (size_t)S.n_tris * sizeof(DevTri) > ((size_t)4 << 20)) : s->opt_pixel_major != 0;
         int guide_shift = 2;                                            // log2(4 x waves of the launch), rounded up
         while ((1ll << guide_shift) < 4ll * trace_blocks * (trace_threads / 64)) ++guide_shift;
         if (!s->opt_guided) guide_shift = 62;
         TraceArgs A{ W.org, W.dir, W.hit, W.state, level == 0 ? (int32_t)kRay1 : (int32_t)kRay2, (long long)s->work.slot_capacity, with_mirror_rays ? 1 : 0,
                      W.n_active, kc, W.head[level], n_lds, stack_cap, (int32_t)s->opt_straggler, chunk, guide_shift,
-                     (int32_t)s->opt_refill_min, (int32_t)s->opt_flush_min, W.stats };
+                     (int32_t)s->opt_refill_min, (int32_t)s->opt_flush_min, (int32_t)pixel_major, W.stats };
         return timed([&] {
             void* kargs[] = { (void*)&S, (void*)&A };
             (void)hipLaunchKernel(trace_fn, dim3(trace_blocks), dim3(trace_threads), kargs, tr_lds, on);
@@ -1563,6 +1565,7 @@ extern "C" int sq_set_option(sq_device_scene* s, const char* key, int64_t value)
     if (!std::strcmp(key, "pool")) { s->opt_pool = value ? 1 : 0; return 0; }
     if (!std::strcmp(key, "guided")) { s->opt_guided = value ? 1 : 0; return 0; }
     if (!std::strcmp(key, "primary_resident")) { s->opt_primary_resident = value ? 1 : 0; return 0; }
+    if (!std::strcmp(key, "pixel_major")) { s->opt_pixel_major = value < 0 ? -1 : value != 0; return 0; }
     if (!std::strcmp(key, "refill_min")) { if (value < 1 || value > 64) return sq_set_error("refill_min must be in 1..64"); s->opt_refill_min = value; return 0; }
     if (!std::strcmp(key, "flush_min")) { if (value < 0 || value > 64) return sq_set_error("flush_min must be in 0..64"); s->opt_flush_min = value; return 0; }
     if (!std::strcmp(key, "aux_blocks_per_cu")) { if (value < 0 || value > 16) return sq_set_error("aux_blocks_per_cu must be in 0..16"); s->opt_aux_blocks_per_cu = value; return 0; }

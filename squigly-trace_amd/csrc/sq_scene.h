@@ -315,15 +315,18 @@ struct HybridNodes {            // first n_lds branches (top of the tree) in LDS
 constexpr uint32_t kResAxisMask = kAxisMask;
 struct ResidentNodes {
     static constexpr bool kBoxInRegisters = false;   // LDS reads are cheap here and VALU is what binds: boxes are read, not tracked
-    const SQ_LDS v4f* quads;      // 2 per branch
+    // (lo, lmax) of all branches, then (hi, rmin) of all branches: a wave's read of either spreads over all 16 bank slots
+    const SQ_LDS v4f* quads; const SQ_LDS v4f* quads_hi;
     const SQ_LDS v2i* refs;       // 1 per branch
+    __device__ __forceinline__ v4f q0(uint32_t b) const { return quads[b]; }
+    __device__ __forceinline__ v4f q1(uint32_t b) const { return quads_hi[b]; }
     __device__ __forceinline__ BranchData load(uint32_t b) const {
         const v2i r = refs[b];
-        return BranchData{ quads[2 * b], quads[2 * b + 1], (int)(((uint32_t)r.x >> 29) & 3u), (uint32_t)r.x & ~kResAxisMask, (uint32_t)r.y };
+        return BranchData{ q0(b), q1(b), (int)(((uint32_t)r.x >> 29) & 3u), (uint32_t)r.x & ~kResAxisMask, (uint32_t)r.y };
     }
     __device__ __forceinline__ BranchTail tail(uint32_t b) const {
         const v2i r = refs[b];
-        return BranchTail{ quads[2 * b].w, quads[2 * b + 1].w, (int)(((uint32_t)r.x >> 29) & 3u), (uint32_t)r.x & ~kResAxisMask, (uint32_t)r.y };
+        return BranchTail{ q0(b).w, q1(b).w, (int)(((uint32_t)r.x >> 29) & 3u), (uint32_t)r.x & ~kResAxisMask, (uint32_t)r.y };
     }
 };
 
@@ -385,14 +388,14 @@ struct ResidentTris {           // whole scene resident in LDS: 16-bit indexed t
         e1 = sq::mk(b.x, b.y, b.z) - v0;
         e2 = sq::mk(c.x, c.y, c.z) - v0;
     }
-    // N consecutive records: 16-byte reads of two records each (ds_read2_b64: the records are 8-byte aligned), offsets unpacked
-    // by VALU -- a third of the LDS instructions of 16-bit reads.  kRunPad zero records follow the last triangle, so a run
+    // N consecutive records, one 8-byte read each, offsets unpacked by VALU -- a third of the LDS instructions of 16-bit reads.  kRunPad zero records follow the last triangle, so a run
     // that starts at any triangle is readable.
     static constexpr int kRunPad = 3;
     template <int N>
     __device__ __forceinline__ void get_run(int i, f3* v0, f3* e1, f3* e2) const {
         typedef unsigned int v2u __attribute__((ext_vector_type(2)));
-        const SQ_LDS v2u* r = reinterpret_cast<const SQ_LDS v2u*>(trix + i);
+        // volatile: separate ds_read_b64 (2 LDS cycles each) rather than the merged ds_read2_b64 (8)
+        const volatile SQ_LDS v2u* r = reinterpret_cast<const volatile SQ_LDS v2u*>(trix + i);
         v2u rec[N];
 #pragma unroll
         for (int k = 0; k < N; ++k) rec[k] = r[k];
@@ -570,10 +573,12 @@ __device__ __forceinline__ void trav_leaf(Trav& T, const TriSrc& G) {
 }
 
 // Return to the caller of the call that just produced R: pop one frame.  Pre: mode == M_UNWIND.
-// `e` is the popped frame; `pre`, when given, is the tail of branch e read ahead of time (FAR frames only).
 template <typename NodeSrc, typename TriSrc, typename StackT>
-__device__ __forceinline__ void trav_unwind_frame(Trav& T, const NodeSrc& N, const TriSrc& G, SQ_LDS StackT* stk, int stride, uint32_t e, const BranchTail* pre, TravProf* prof = nullptr) {
+__device__ __forceinline__ void trav_unwind(Trav& T, const NodeSrc& N, const TriSrc& G, SQ_LDS StackT* stk, int stride, TravProf* prof = nullptr) {
     constexpr uint32_t flag = StackTraits<StackT>::flag;
+    if (T.sp == 0) { T.mode = M_DONE; return; }
+    --T.sp;
+    const uint32_t e = stk[T.sp * stride];
     if (e & flag) {                                                     // minimumByMay over [near, far] (src/BIH.hs:115,120)
         const int32_t ntri = (int32_t)(e & ~flag);
         float nt = T.ct;
@@ -594,7 +599,7 @@ __device__ __forceinline__ void trav_unwind_frame(Trav& T, const NodeSrc& N, con
         const BranchData D = N.load(e);                                 // this branch's own box again; the far child's follows below
         T.blo = sq::mk(D.q0.x, D.q0.y, D.q0.z); T.bhi = sq::mk(D.q1.x, D.q1.y, D.q1.z);
         B = BranchTail{ D.q0.w, D.q1.w, D.axis, D.left, D.right };
-    } else B = pre ? *pre : N.tail(e);
+    } else B = N.tail(e);
     const int ax = B.axis;
     const bool l2r = sq::axis_of(T.d, ax) > 0;
     if (T.R.tri >= 0) {
@@ -610,13 +615,6 @@ __device__ __forceinline__ void trav_unwind_frame(Trav& T, const NodeSrc& N, con
         else     { if (ax == 0) T.bhi.x = B.lmax; else if (ax == 1) T.bhi.y = B.lmax; else T.bhi.z = B.lmax; }
     }
     T.mode = (T.cur & kLeafBit) ? M_LEAF : M_DESCEND;
-}
-
-template <typename NodeSrc, typename TriSrc, typename StackT>
-__device__ __forceinline__ void trav_unwind(Trav& T, const NodeSrc& N, const TriSrc& G, SQ_LDS StackT* stk, int stride, TravProf* prof = nullptr) {
-    if (T.sp == 0) { T.mode = M_DONE; return; }
-    --T.sp;
-    trav_unwind_frame(T, N, G, stk, stride, (uint32_t)stk[T.sp * stride], nullptr, prof);
 }
 
 // Whole query, one ray per lane (used where rays of a wave are coherent: primary and shadow rays).
