@@ -119,7 +119,10 @@ int  sq_get_stats(sq_device_scene* s, uint64_t* out, int32_t n, int32_t reset);
  *                            kernels beside them on an internal stream
  *                        2 = two pipelines: even and odd sample batches run start to end on two streams, so that one
  *                            track's launches fill the other's ramp-downs (+1.9 % on the headline frame)
- *   "aux_blocks_per_cu"  workgroups per CU of the per-sample kernels (0 = default 8) */
+ *   "aux_blocks_per_cu"  workgroups per CU of the per-sample kernels (0 = default 8)
+ *   "cull"               1 (default): a ray inside the limits of sq_cull_boxes (squigly_host.h) that misses a leaf's culling box
+ *                        skips the leaf's triangle tests -- the reference's mollerTrumbore would reject them all, so no bit
+ *                        changes; 0: every leaf the reference visits is tested */
 int  sq_set_option(sq_device_scene* s, const char* key, int64_t value);
 
 /* Diagnostics for the numeric spec (tests only): evaluate one primitive on the device for n inputs.
@@ -130,9 +133,11 @@ int  sq_set_option(sq_device_scene* s, const char* key, int64_t value);
  *   SQ_OP_TONEMAP                : a = 3n floats -> out = 3n bytes (src/Lib.hs:93-104)
  *   SQ_OP_RCP_SWEEP              : a = n uint32 (upper 16 bits of a float) -> out = n uint32: among the 65536 floats x with
  *                                  those upper bits, how many have the triangle test's short reciprocal != 1.0f / x
+ *   SQ_OP_CULL_SLAB              : a = 9n words (a culling box as three packed binary16 pairs lo | hi << 16 for x, y, z; ray
+ *                                  origin; ray direction) -> out = n uint32: 1 if the ray passes the kernels' culling slab test
  * a, b, out are HOST pointers. */
 enum { SQ_OP_SQRT = 0, SQ_OP_DIV = 1, SQ_OP_SIN = 2, SQ_OP_COS = 3, SQ_OP_ACOS = 4, SQ_OP_ATAN = 5,
-       SQ_OP_UNIT_FLOAT = 6, SQ_OP_TFGEN3 = 7, SQ_OP_TONEMAP = 8, SQ_OP_RCP_SWEEP = 9 };
+       SQ_OP_UNIT_FLOAT = 6, SQ_OP_TFGEN3 = 7, SQ_OP_TONEMAP = 8, SQ_OP_RCP_SWEEP = 9, SQ_OP_CULL_SLAB = 10 };
 int sq_debug_eval(int32_t device, int32_t op, const void* a, const void* b, int64_t n, void* out);
 
 int32_t     sq_device_count(void);

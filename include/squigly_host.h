@@ -48,6 +48,16 @@ int32_t sq_bih_num_leaves(const sq_bih* b);    /* BIH.numLeaves    src/BIH.hs:54
 int32_t sq_bih_longest_leaf(const sq_bih* b);  /* BIH.longestLeaf  src/BIH.hs:58-60 */
 void sq_bih_free(sq_bih* b);
 
+/* Culling boxes (no counterpart in the reference; an exact reduction of its triangle tests).  boxes: 6 floats per node
+ * of scene->nodes (lo.xyz, hi.xyz; a branch gets the union of its children).  A ray with ray_limits[1] <= |d|^2 <=
+ * ray_limits[2], |o|^2 <= ray_limits[0] and finite o, d, 1/d, o/d that FAILS the fp32 slab test of a node's box is
+ * rejected by the reference's mollerTrumbore (src/Geometry.hs:117-142) for every triangle of that node, so the node
+ * returns Nothing (src/BIH.hs:105-109) without testing them.  The error analysis is in csrc/sq_host.cpp; leaves it does
+ * not cover get an infinite box, and ray_limits[0] < 0 says no ray may be culled.  sq_scene_upload() calls this. */
+int  sq_cull_boxes(const sq_scene* scene, float* boxes, float ray_limits[3]);
+/* The binary16 encoding the resident kernels keep such a box in: the nearest value >= x (up != 0) or <= x, never subnormal. */
+uint32_t sq_half_outward(float x, int32_t up);
+
 #ifdef __cplusplus
 }
 #endif

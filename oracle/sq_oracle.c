@@ -432,6 +432,9 @@ void sqo_intersect_bih(const sqo_bih* b, sqo_v3 o, sqo_v3 d, sqo_hit* out, sqo_c
     c->rays++;
     *out = isect_rec(b->bounds, b->tree, o, d, c);
     if (out->hit) c->hits++;
+#ifdef SQO_RAY_HOOK              /* experiments under tests/ that include this file observe every ray and its result */
+    SQO_RAY_HOOK(b, o, d, out);
+#endif
 }
 static void naive_rec(const node* nd, V3 o, V3 d, sqo_hit* best) {
     if (nd->kind == 3) {

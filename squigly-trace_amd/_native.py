@@ -102,6 +102,9 @@ def lib():
     L.sq_release_cached_memory.restype = None
     L.sq_bih_build.argtypes = [vp, C.POINTER(vp)]
     L.sq_bih_build_device.argtypes = [vp, C.c_int32, C.POINTER(vp)]
+    L.sq_cull_boxes.argtypes = [C.POINTER(Scene), vp, vp]
+    L.sq_half_outward.argtypes = [C.c_float, i32]
+    L.sq_half_outward.restype = C.c_uint32
     L.sq_bih_scene.argtypes = [vp, C.POINTER(Scene)]
     L.sq_bih_scene.restype = None
     for f in ("height", "num_leaves", "longest_leaf"):
@@ -113,7 +116,7 @@ def lib():
     return L
 
 
-OPS = {"sqrt": 0, "div": 1, "sin": 2, "cos": 3, "acos": 4, "atan": 5, "unit_float": 6, "tfgen3": 7, "tonemap": 8, "rcp_sweep": 9}
+OPS = {"sqrt": 0, "div": 1, "sin": 2, "cos": 3, "acos": 4, "atan": 5, "unit_float": 6, "tfgen3": 7, "tonemap": 8, "rcp_sweep": 9, "cull_slab": 10}
 
 
 def debug_eval(op, a, b=None, device=0):
@@ -125,6 +128,8 @@ def debug_eval(op, a, b=None, device=0):
         a = np.ascontiguousarray(a, np.float32).reshape(-1, 3); n = len(a); out = np.empty((n, 3), np.uint8)
     elif op == "unit_float":
         a = np.ascontiguousarray(a, np.uint32); n = a.size; out = np.empty(n, np.float32)
+    elif op == "cull_slab":
+        a = np.ascontiguousarray(a, np.uint32).reshape(-1, 9); n = len(a); out = np.empty(n, np.uint32)
     elif op == "rcp_sweep":
         a = np.ascontiguousarray(a, np.uint32); n = a.size; out = np.empty(n, np.uint32)
     else:
@@ -148,6 +153,6 @@ EXPORTED_SYMBOLS = [
     # include/squigly_host.h
     "sq_mesh_from_obj", "sq_mesh_from_text", "sq_mesh_from_arrays", "sq_mesh_num_tris",
     "sq_mesh_num_materials", "sq_mesh_tris", "sq_mesh_materials", "sq_mesh_free", "sq_camera_from_file",
-    "sq_camera_from_text", "sq_rot_matrix_rads", "sq_release_cached_memory", "sq_mesh_debug_show", "sq_bih_build", "sq_bih_build_device", "sq_bih_scene", "sq_bih_height",
+    "sq_camera_from_text", "sq_rot_matrix_rads", "sq_release_cached_memory", "sq_mesh_debug_show", "sq_bih_build", "sq_bih_build_device", "sq_cull_boxes", "sq_half_outward", "sq_bih_scene", "sq_bih_height",
     "sq_bih_num_leaves", "sq_bih_longest_leaf", "sq_bih_free",
 ]

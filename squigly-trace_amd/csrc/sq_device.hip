@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -29,6 +30,7 @@
 #include <vector>
 
 #include "../../include/squigly_hip.h"
+#include "../../include/squigly_host.h"
 #include "sq_error.h"
 #include "sq_scene.h"
 
@@ -467,8 +469,8 @@ __device__ __forceinline__ void stage_resident_scene(const SceneView& S, int n_b
         lt[i] = v4us{ (unsigned short)(t.x * 16u), (unsigned short)(t.y * 16u), (unsigned short)(t.z * 16u), t.w };
     }
     if (threadIdx.x < ResidentTris::kRunPad) lt[S.n_tris + threadIdx.x] = v4us{ 0, 0, 0, 0 };
-    N = ResidentNodes{ lquads, lquads + n_branches, lrefs };
-    G = ResidentTris{ lt };
+    N = ResidentNodes{ lquads, lquads + n_branches, lrefs, S.cull_resident != 0 };
+    G = ResidentTris{ lt, S.cull_resident ? ResidentNodes::kFirstMask : 0xFFFFFFu };
     if ((uintptr_t)lv != 0) __builtin_trap();                              // the kernels that use this have no static LDS: dynamic LDS starts at address 0
 }
 
@@ -858,6 +860,12 @@ __global__ void sq_debug_kernel(int op, const void* a, const void* b, long long 
             }
             ((uint32_t*)out)[i] = bad; break;
         }
+        case SQ_OP_CULL_SLAB: {                                            // the culling slab test as the trace kernels run it
+            const uint32_t* w = (const uint32_t*)a + 9 * i; const float* r = fa + 9 * i + 3;
+            const f3 o = sq::mk(r[0], r[1], r[2]), d = sq::mk(r[3], r[4], r[5]);
+            const f3 df = sq::mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z), nodf = sq::mk(-o.x * df.x, -o.y * df.y, -o.z * df.z);
+            ((uint32_t*)out)[i] = cull_slab_half(w[0], w[1], w[2], df, nodf) ? 1u : 0u; break;
+        }
         default: break;
     }
 }
@@ -881,7 +889,7 @@ struct sq_device_scene {
     // second stream of the overlapped schedule (launch_frame) and its event pool
     hipStream_t aux = nullptr; std::vector<hipEvent_t> events;
     int64_t opt_overlap = 0, opt_aux_blocks_per_cu = 0;
-    int64_t opt_pool = 1, opt_refill_min = 12, opt_flush_min = 40, opt_guided = 1, opt_primary_resident = 1, opt_pixel_major = -1;
+    int64_t opt_pool = 1, opt_refill_min = 12, opt_flush_min = 40, opt_guided = 1, opt_primary_resident = 1, opt_pixel_major = -1, opt_cull = 1;
 };
 
 namespace {
@@ -1046,15 +1054,32 @@ extern "C" int sq_scene_upload(const sq_scene* sc, int32_t device, sq_device_sce
             }
         } else { uverts.clear(); }
     }
+    // Culling boxes (include/squigly_host.h: sq_cull_boxes), per pre-order node.
+    std::vector<float> cbox((size_t)n * 6); float cull_limits[3] = { -1.0f, 0.25f, 1.5624f };
+    if (sq_cull_boxes(sc, cbox.data(), cull_limits)) return 1;
     // Resident encoding of the branches (see sq_scene.h): needs encodable leaves and a 24-bit index space.
-    std::vector<uint32_t> rbranch; uint32_t rroot = 0;
+    std::vector<uint32_t> rbranch; uint32_t rroot = 0; bool cull_resident = false;
     {
         bool ok = !trix.empty() && nb < (1 << 24) && sc->n_tris < (1 << 24);
         for (int32_t i = 0; i < nl && ok; ++i) ok = lf[(size_t)i].count <= 31;
+        // Leaf culling in the resident form: leaf k's box as six binary16 values (rounded outwards, never subnormal) in the w
+        // words of vertices 3k..3k+2, its slot k in bits 23..13 of the leaf reference (ResidentNodes::child_hit).
+        cull_resident = ok && cull_limits[0] >= 0.0f && sc->n_tris <= (int32_t)ResidentNodes::kFirstMask + 1 &&
+                        nl <= (int32_t)ResidentNodes::kSlotMask + 1 && (size_t)3 * (size_t)nl <= uverts.size() / 4;
+        if (cull_resident) {
+            for (int32_t i = 0; i < n; ++i) {
+                if ((sc->nodes[i].kind & 3) != 3) continue;
+                const uint32_t k = ref[(size_t)i] & ~kLeafBit; const float* b = &cbox[(size_t)i * 6];
+                for (int c = 0; c < 3; ++c) {
+                    const uint32_t w = sq_half_outward(b[c], 0) | (sq_half_outward(b[3 + c], 1) << 16);
+                    std::memcpy(&uverts[((size_t)3 * k + (size_t)c) * 4 + 3], &w, 4);
+                }
+            }
+        }
         auto enc = [&](uint32_t r) -> uint32_t {
             if (!(r & kLeafBit)) return r;
             const DevLeaf& L = lf[r & ~kLeafBit];
-            return kLeafBit | ((uint32_t)L.count << 24) | (uint32_t)L.first;
+            return kLeafBit | ((uint32_t)L.count << 24) | (cull_resident ? ((r & ~kLeafBit) << ResidentNodes::kSlotShift) : 0u) | (uint32_t)L.first;
         };
         if (ok) {
             rbranch.resize((size_t)nb * 10);
@@ -1065,7 +1090,7 @@ extern "C" int sq_scene_upload(const sq_scene* sc, int32_t device, sq_device_sce
                 r[8] = enc(d.left) | ((uint32_t)br_axis[(size_t)i] << 29); r[9] = enc(d.right);
             }
             rroot = enc(ref[0]);
-        } else { trix.clear(); }
+        } else { trix.clear(); cull_resident = false; }
     }
     // Streaming form: leaf references carry (first, count) themselves when they fit, which saves the dependent
     // leaf-table load of every leaf visit.
@@ -1139,6 +1164,8 @@ extern "C" int sq_scene_upload(const sq_scene* sc, int32_t device, sq_device_sce
     v.verts4 = (const float4*)s->d_verts; v.trix = trix.empty() ? nullptr : (const ushort4*)s->d_trix; v.n_verts = (int32_t)(uverts.size() / 4);
     v.rbranch = (const uint32_t*)s->d_rbranch; v.rroot = rroot;
     v.emitters = (const int32_t*)s->d_emitters; v.n_emitters = n_emitters;
+    v.cull_o2max = cull_limits[0]; v.cull_d2min = cull_limits[1]; v.cull_d2max = cull_limits[2];
+    v.cull_resident = cull_resident ? 1 : 0; v.cull_child = nullptr;
     *out = s;
     return 0;
 }
@@ -1251,7 +1278,8 @@ int ensure_workspace(sq_device_scene* s, int64_t pixels, int64_t slots) {
 
 template <typename StackT>
 int launch_frame(sq_device_scene* s, const Frame& F, hipStream_t stream) {
-    const SceneView& S = s->view;
+    SceneView S = s->view;
+    if (!s->opt_cull) S.cull_o2max = -1.0f;                            // no ray is inside the culling limits: every leaf is tested
     const long long pixels = (long long)F.local_rows * F.h;
     const int stack_cap = std::max(S.height, 1);
     const size_t px_lds = (size_t)kBlock * stack_cap * sizeof(StackT);
@@ -1565,6 +1593,7 @@ extern "C" int sq_set_option(sq_device_scene* s, const char* key, int64_t value)
     if (!std::strcmp(key, "pool")) { s->opt_pool = value ? 1 : 0; return 0; }
     if (!std::strcmp(key, "guided")) { s->opt_guided = value ? 1 : 0; return 0; }
     if (!std::strcmp(key, "primary_resident")) { s->opt_primary_resident = value ? 1 : 0; return 0; }
+    if (!std::strcmp(key, "cull")) { s->opt_cull = value ? 1 : 0; return 0; }
     if (!std::strcmp(key, "pixel_major")) { s->opt_pixel_major = value < 0 ? -1 : value != 0; return 0; }
     if (!std::strcmp(key, "refill_min")) { if (value < 1 || value > 64) return sq_set_error("refill_min must be in 1..64"); s->opt_refill_min = value; return 0; }
     if (!std::strcmp(key, "flush_min")) { if (value < 0 || value > 64) return sq_set_error("flush_min must be in 0..64"); s->opt_flush_min = value; return 0; }
@@ -1682,13 +1711,13 @@ extern "C" int sq_render_f32(const sq_scene* scene, const sq_camera* cam, int32_
 }
 
 extern "C" int sq_debug_eval(int32_t device, int32_t op, const void* a, const void* b, int64_t n, void* out) {
-    if (!a || !out || n < 0 || op < 0 || op > SQ_OP_RCP_SWEEP) return sq_set_error("bad argument");
+    if (!a || !out || n < 0 || op < 0 || op > SQ_OP_CULL_SLAB) return sq_set_error("bad argument");
     if (op == SQ_OP_DIV && !b) return sq_set_error("SQ_OP_DIV needs b");
     if (n == 0) return 0;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return sq_set_error("no such HIP device %d", device);
     SQ_HIP(hipSetDevice(device));
-    const size_t in_sz = (size_t)n * (op == SQ_OP_TFGEN3 ? 8 : op == SQ_OP_TONEMAP ? 12 : 4);
+    const size_t in_sz = (size_t)n * (op == SQ_OP_TFGEN3 ? 8 : op == SQ_OP_TONEMAP ? 12 : op == SQ_OP_CULL_SLAB ? 36 : 4);
     const size_t out_sz = (size_t)n * (op == SQ_OP_TFGEN3 ? 12 : op == SQ_OP_TONEMAP ? 3 : 4);
     void *da = nullptr, *db = nullptr, *dout = nullptr;
     auto body = [&]() -> int {

@@ -11,6 +11,7 @@
 #include "sq_math.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -443,3 +444,106 @@ extern "C" int32_t sq_bih_height(const sq_bih* b) { return b->height; }
 extern "C" int32_t sq_bih_num_leaves(const sq_bih* b) { return b->leaves; }
 extern "C" int32_t sq_bih_longest_leaf(const sq_bih* b) { return b->longest; }
 extern "C" void sq_bih_free(sq_bih* b) { delete b; }
+
+// ---- Culling boxes: an exact reduction of the triangle tests (no counterpart in the reference) ----------------------
+// A Leaf equation (src/BIH.hs:105-109) returns Nothing unless mollerTrumbore accepts one of its triangles.  The BIH only
+// clips along split axes, so most leaves a ray visits are far from it: sq_cull_boxes() gives every node a box such that
+//
+//     a ray within the limits below whose fp32 mollerTrumbore (src/Geometry.hs:117-142, round-to-nearest, no FMA)
+//     ACCEPTS some triangle of the node  ==>  the ray passes the fp32 slab test of the node's box,
+//
+// so a ray that fails the slab test can skip the node's triangles and the node still returns exactly what the reference
+// returns (Nothing).  The box is the triangles' bounding box grown by a margin m that covers the rounding of the
+// accepted test.  Derivation (u = 2^-24, eps = 0.0001f, s = o - v0, E1 = |e1|, E2 = |e2|, D >= |d|, S >= |s|, P = E1 E2 D;
+// h = d x e2, a = e1.h, Nu = s.h, q = s x e1, Nv = d.q, Nt = e2.q; hats are the computed values):
+//   |h^ - h|_2 <= 3.5u D E2 (two products and a difference per component), dot products are within 3.01u |x||y|, so
+//   |a^ - a| <= 7u P,  |Nu^ - Nu| <= 8u S D E2,  |Nv^ - Nv| <= 8u S D E1,  |Nt^ - Nt| <= 8u S E1 E2.
+//   Acceptance means |a^| >= eps, 0 <= u^ <= 1, 0 <= v^, u^ + v^ <= 1 (+u), t^ > eps.  With r = 7uP/eps <= 1/8 (P <= 29)
+//   a and a^ have one sign and the exact solution (u, v, t) of  o + t d = v0 + u e1 + v e2  satisfies
+//   |u - u^| <= 1.15 (r + 8u S D E2/eps) + 2.01u, the same for v with E1, and t > -1.15 * 8u S E1 E2 / eps.
+//   So the point X = v0 + u e1 + v e2 lies on the ray's LINE at parameter t and within |u-u^| E1 + |v-v^| E2 of the
+//   triangle; if t < 0 the origin is within |t| D of X.  Either way a point of the ray with t >= 0 lies within
+//       rho = 28 (u/eps) P (S + E1 + E2) + 5u (E1 + E2)
+//   of the triangle (the last term also covers e1 = fl(v1 - v0)).  The margin uses 32 and 6.
+//   Slab test: with df = fl(1/d), nodf = fl(-o df) and plane value fma(l, df, nodf) (or fl(fl(l - o) df)) every plane
+//   value is within 4u (|l| + |o|)/|d_k| of the exact one, so growing the box by a further 8u (|l| + |o|) makes every
+//   computed interval contain the exact interval of the rho-box with room to spare: an exact hit of the rho-box passes
+//   `tmax > 0 && tmin < tmax`.  Subnormal results add at most 2^-149 per operation, far below the floor added at the end.
+// Limits under which this holds (rays outside them are simply not culled; leaves outside them get an infinite box):
+//   every coordinate finite and <= 2^20 in magnitude (no overflow anywhere in the test), P <= 29 for every triangle of
+//   the leaf, 0.25 <= |d|^2 <= 1.5624 (primary rays have |d| <= 1.2248, bounce rays |d| = 1 or the incoming length), |o|^2 <= o2max
+//   = (2 max|vertex|)^2, and o, d, 1/d, o/d finite.
+// tests/test_cull.py searches for violations with adversarial grazing rays against exact (binary64 / rational) geometry.
+namespace {
+inline float f_down(double x) { float f = (float)x; if ((double)f > x) f = std::nextafterf(f, -INFINITY); return f; }
+inline float f_up(double x) { float f = (float)x; if ((double)f < x) f = std::nextafterf(f, INFINITY); return f; }
+}
+extern "C" int sq_cull_boxes(const sq_scene* sc, float* boxes, float ray_limits[3]) {
+    if (!sc || !boxes || !ray_limits) return sq_set_error("null argument");
+    const int32_t n = sc->n_nodes;
+    const double u = 5.9604644775390625e-8, eps = (double)0.0001f, kD = 1.25, kPmax = 29.0;
+    const float inf = INFINITY;
+    auto disable = [&]() { for (int32_t i = 0; i < n; ++i) { float* b = boxes + 6 * (size_t)i; b[0] = b[1] = b[2] = -inf; b[3] = b[4] = b[5] = inf; }
+                           ray_limits[0] = -1.0f; ray_limits[1] = 0.25f; ray_limits[2] = 1.5624f; return 0; };
+    double vmax_inf = 0.0, vmax2 = 0.0;
+    for (int32_t i = 0; i < sc->n_tris; ++i) {
+        const float* vs[3] = { sc->tris[i].v0, sc->tris[i].v1, sc->tris[i].v2 };
+        for (const float* v : vs) {
+            double q = 0.0;
+            for (int c = 0; c < 3; ++c) { if (!(v[c] - v[c] == 0.0f)) return disable(); vmax_inf = std::max(vmax_inf, std::fabs((double)v[c])); q += (double)v[c] * v[c]; }
+            vmax2 = std::max(vmax2, q);
+        }
+    }
+    if (sc->n_tris == 0 || vmax_inf > 1048576.0) return disable();
+    const double omax = 2.0 * std::sqrt(vmax2) * (1.0 + 1e-12);
+    ray_limits[0] = f_down(omax * omax * (1.0 - 1e-6)); ray_limits[1] = 0.25f; ray_limits[2] = 1.5624f;
+    for (int32_t i = n - 1; i >= 0; --i) {                          // children come after their parent in pre-order
+        const sq_node& nd = sc->nodes[i];
+        float* b = boxes + 6 * (size_t)i;
+        if ((nd.kind & 3) != 3) {
+            const float* l = boxes + 6 * (size_t)(i + 1); const float* r = boxes + 6 * (size_t)nd.link;
+            for (int c = 0; c < 3; ++c) { b[c] = std::min(l[c], r[c]); b[3 + c] = std::max(l[3 + c], r[3 + c]); }
+            continue;
+        }
+        const int32_t first = nd.link, cnt = nd.kind >> 2;
+        double lo[3] = { 1e300, 1e300, 1e300 }, hi[3] = { -1e300, -1e300, -1e300 }, m = 0.0; bool ok = cnt > 0;
+        for (int32_t k = first; k < first + cnt && ok; ++k) {
+            const sq_tri& t = sc->tris[k];
+            double E1 = 0, E2 = 0, V0 = 0;
+            for (int c = 0; c < 3; ++c) {
+                const float e1 = t.v1[c] - t.v0[c], e2 = t.v2[c] - t.v0[c];        // the kernels' edges (src/Geometry.hs:130-131)
+                E1 += (double)e1 * e1; E2 += (double)e2 * e2; V0 += (double)t.v0[c] * t.v0[c];
+                for (const float* v : { t.v0, t.v1, t.v2 }) { lo[c] = std::min(lo[c], (double)v[c]); hi[c] = std::max(hi[c], (double)v[c]); }
+            }
+            E1 = std::sqrt(E1); E2 = std::sqrt(E2); V0 = std::sqrt(V0);
+            const double P = E1 * E2 * kD;
+            if (!(P <= kPmax)) { ok = false; break; }
+            m = std::max(m, 32.0 * (u / eps) * P * (omax + V0 + E1 + E2) + 6.0 * u * (E1 + E2));
+        }
+        if (!ok) { b[0] = b[1] = b[2] = -inf; b[3] = b[4] = b[5] = inf; continue; }
+        m += 8.0 * u * (vmax_inf + m + omax) + 1e-20;
+        for (int c = 0; c < 3; ++c) { b[c] = f_down(lo[c] - m); b[3 + c] = f_up(hi[c] + m); }
+    }
+    return 0;
+}
+
+// The binary16 value nearest to x on the side asked for (up: >= x, else <= x), never a subnormal: +-2^-14 or zero instead,
+// so that the device's handling of binary16 denormals cannot matter.  NaN gives the infinity of that side.
+extern "C" uint32_t sq_half_outward(float x, int32_t up_) {
+    const bool up = up_ != 0;
+    if (!(x == x)) return up ? 0x7C00u : 0xFC00u;
+    const bool neg = std::signbit(x); const double ax = std::fabs((double)x);
+    const bool mag_up = up != neg;                           // round the magnitude away from zero?
+    uint32_t hb;
+    if (ax == 0.0) hb = 0;
+    else if (ax > 65504.0) hb = (mag_up || std::isinf(ax)) ? 0x7C00u : 0x7BFFu;
+    else if (ax < 6.103515625e-05) hb = mag_up ? 0x0400u : 0u;
+    else {
+        int e; const double mant = std::frexp(ax, &e) * 2.0; e -= 1;     // ax = mant * 2^e, mant in [1, 2)
+        const double m10 = mant * 1024.0 - 1024.0; const double fl = std::floor(m10);
+        uint32_t q = (uint32_t)fl + ((mag_up && fl != m10) ? 1u : 0u);
+        if (q == 1024u) { q = 0; ++e; }
+        hb = e > 15 ? 0x7C00u : (((uint32_t)(e + 15) << 10) | q);
+    }
+    return neg ? (hb | 0x8000u) : hb;
+}

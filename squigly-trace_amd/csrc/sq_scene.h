@@ -63,6 +63,11 @@ struct SceneView {
     int32_t finite_geometry;  // 1 if every vertex and box coordinate is finite (v_min/v_max slabs need NaN-free planes)
     const int32_t* emitters;  // triangles whose emission `emissive *^ emitColor` is not exactly (+0,+0,+0)
     int32_t n_emitters;       // their number, or -1 when the last-bounce shortcut is disabled (see sq_shade1)
+    // Leaf culling (sq_cull_boxes, include/squigly_host.h): a ray inside these limits that misses a leaf's culling box
+    // skips the leaf's triangles -- mollerTrumbore would reject them all.  cull_o2max < 0: nothing is culled.
+    float cull_o2max, cull_d2min, cull_d2max;
+    int32_t cull_resident;    // 1: resident leaf references carry a box slot (bits 23..13) and the boxes sit in the vertices' w words
+    const float* cull_child;  // streaming form: 12 floats per branch, the culling boxes of its left and right child; or nullptr
 };
 
 struct Hit { float t; int32_t tri; };   // tri < 0 : Nothing.  dist is derived from t on demand (hit_dist)
@@ -178,6 +183,27 @@ __device__ __forceinline__ bool dist_gt(f3 o, f3 d, float ta, float tb, bool fin
     return sq::cmp_gt(hit_dist(o, d, ta), hit_dist(o, d, tb));
 }
 
+// Culling slab test (my own test, not the reference's intersectsBB): plane values in FMA form, l * (1/d) + (-o/d).
+// v_fma_mix_f32 takes the plane straight from a packed pair of binary16 values (exact conversion, one rounding).
+__device__ __forceinline__ float fma_mix_lo(uint32_t h, float b, float c) { float r; asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float fma_mix_hi(uint32_t h, float b, float c) { float r; asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ bool cull_slab_half(uint32_t wx, uint32_t wy, uint32_t wz, f3 df, f3 nodf) {   // w = lo | hi << 16 per axis
+    const float t1 = fma_mix_lo(wx, df.x, nodf.x), t2 = fma_mix_hi(wx, df.x, nodf.x);
+    const float t3 = fma_mix_lo(wy, df.y, nodf.y), t4 = fma_mix_hi(wy, df.y, nodf.y);
+    const float t5 = fma_mix_lo(wz, df.z, nodf.z), t6 = fma_mix_hi(wz, df.z, nodf.z);
+    const float tmin = vmax3(vmin(t1, t2), vmin(t3, t4), vmin(t5, t6));
+    const float tmax = vmin3(vmax(t1, t2), vmax(t3, t4), vmax(t5, t6));
+    return tmax > 0 && tmin < tmax;
+}
+__device__ __forceinline__ bool cull_slab(const float* b, f3 df, f3 nodf) {                                 // b = lo.xyz, hi.xyz
+    const float t1 = __builtin_fmaf(b[0], df.x, nodf.x), t2 = __builtin_fmaf(b[3], df.x, nodf.x);
+    const float t3 = __builtin_fmaf(b[1], df.y, nodf.y), t4 = __builtin_fmaf(b[4], df.y, nodf.y);
+    const float t5 = __builtin_fmaf(b[2], df.z, nodf.z), t6 = __builtin_fmaf(b[5], df.z, nodf.z);
+    const float tmin = vmax3(vmin(t1, t2), vmin(t3, t4), vmin(t5, t6));
+    const float tmax = vmin3(vmax(t1, t2), vmax(t3, t4), vmax(t5, t6));
+    return tmax > 0 && tmin < tmax;
+}
+
 struct Surface {            // what shading needs from a hit triangle
     f3 n;                   // normal = e1 x e2, un-normalised (src/Geometry.hs:79-80)
     float reflective; f3 surf; f3 emit;   // emit = emissive *^ emitColor (src/Lib.hs:136)
@@ -275,6 +301,7 @@ __device__ __forceinline__ BranchData unpack_branch(v4f q0, v4f q1, v4f q2) {
 }
 struct GlobalNodes {            // every branch read from HBM/L2
     static constexpr bool kBoxInRegisters = false;
+    static constexpr bool kCull = false;
     const float4* g;
     __device__ __forceinline__ BranchData load(uint32_t b) const {
         const float4 a = g[3 * b], c = g[3 * b + 1], d = g[3 * b + 2];
@@ -297,6 +324,7 @@ struct HybridNodes {            // first n_lds branches (top of the tree) in LDS
 #define SQ_BOX_IN_REGISTERS 0
 #endif
     static constexpr bool kBoxInRegisters = SQ_BOX_IN_REGISTERS != 0;
+    static constexpr bool kCull = false;
     const SQ_LDS v4f* l; const float4* g; uint32_t n_lds;
     __device__ __forceinline__ BranchData load(uint32_t b) const {
         if (b < n_lds) return unpack_branch(l[3 * b], l[3 * b + 1], l[3 * b + 2]);
@@ -318,6 +346,18 @@ struct ResidentNodes {
     // (lo, lmax) of all branches, then (hi, rmin) of all branches: a wave's read of either spreads over all 16 bank slots
     const SQ_LDS v4f* quads; const SQ_LDS v4f* quads_hi;
     const SQ_LDS v2i* refs;       // 1 per branch
+    // Leaf culling: with cull_on a leaf reference carries a box slot in bits 23..13 and the first triangle in bits 12..0.
+    // Slot k's box is six binary16 values in the otherwise unused w words of vertices 3k, 3k+1, 3k+2 (the vertex table
+    // starts at LDS address 0): lo.x | hi.x << 16, then y, then z.  The scene's 127 KB leave no room for a table of its own.
+    static constexpr bool kCull = true;
+    static constexpr uint32_t kSlotShift = 13, kSlotMask = 0x7FFu, kFirstMask = 0x1FFFu;
+    bool cull_on;
+    __device__ __forceinline__ bool child_hit(uint32_t, bool, uint32_t ref, f3 df, f3 nodf) const {
+        if (!(ref & kLeafBit)) return true;                              // only leaves have boxes here
+        const uint32_t slot = (ref >> kSlotShift) & kSlotMask;
+        const SQ_LDS uint32_t* p = reinterpret_cast<const SQ_LDS uint32_t*>((uintptr_t)(slot * 48u + 12u));
+        return cull_slab_half(p[0], p[4], p[8], df, nodf);
+    }
     __device__ __forceinline__ v4f q0(uint32_t b) const { return quads[b]; }
     __device__ __forceinline__ v4f q1(uint32_t b) const { return quads_hi[b]; }
     __device__ __forceinline__ BranchData load(uint32_t b) const {
@@ -378,6 +418,7 @@ struct ResidentTris {           // whole scene resident in LDS: 16-bit indexed t
     // vertex address is the record field itself, no shift and no base add (integer VALU ops cost 4.2 cycles here
     // against 2.5 for an fp32 multiply, tools/ubench/op_rate.hip).
     const SQ_LDS v4us* trix;
+    uint32_t first_mask;      // bits of a leaf reference that hold its first triangle (the rest of bits 23..0 is a culling-box slot)
     __device__ __forceinline__ v4f vertex(unsigned off) const { return *reinterpret_cast<const SQ_LDS v4f*>((uintptr_t)off); }   // LDS address = offset (table at LDS address 0)
     __device__ __forceinline__ void get(int i, f3& v0, f3& e1, f3& e2) const { get_indexed(trix[i], v0, e1, e2); }
     __device__ __forceinline__ void get1(int i, f3& v0, f3& e1, f3& e2) const {    // three 16-bit reads: the offsets arrive zero-extended
@@ -412,7 +453,7 @@ struct ResidentTris {           // whole scene resident in LDS: 16-bit indexed t
         e1 = sq::mk(b.x, b.y, b.z) - v0;
         e2 = sq::mk(c.x, c.y, c.z) - v0;
     }
-    __device__ __forceinline__ int2 leaf(uint32_t ref) const { return make_int2((int)(ref & 0xFFFFFFu), (int)((ref >> 24) & 31u)); }
+    __device__ __forceinline__ int2 leaf(uint32_t ref) const { return make_int2((int)(ref & first_mask), (int)((ref >> 24) & 31u)); }
 };
 
 // ---- wave64 prefix scans on the DPP network (gfx9 DPP: row_shr inside rows of 16 lanes, then row_bcast:15 and
@@ -460,6 +501,8 @@ struct Trav {
     int csp;            // stack index of the COMBINE frame whose t is cached below, or -1
     float ct;
     f3 blo, bhi;        // NodeSrc::kBoxInRegisters: traversal box of the node `cur` (unused otherwise)
+    bool cull;          // the ray is inside the limits of sq_cull_boxes: a node whose culling box it misses returns Nothing
+    f3 nodf;            // -o * (1/d), for the culling slab test in FMA form
 };
 
 __device__ __forceinline__ void trav_begin(Trav& T, const SceneView& S, uint32_t root_ref, f3 o, f3 d) {
@@ -467,6 +510,11 @@ __device__ __forceinline__ void trav_begin(Trav& T, const SceneView& S, uint32_t
     T.cur = root_ref; T.sp = 0; T.R.t = 0; T.R.tri = -1;
     T.safe = S.finite_geometry && finite3(o) && finite3(d) && finite3(T.df);
     T.csp = -1; T.ct = 0;
+    T.nodf = sq::mk(-o.x * T.df.x, -o.y * T.df.y, -o.z * T.df.z);
+    {   // limits of the culling lemma (sq_cull_boxes): |o|^2 <= o2max, d2min <= |d|^2 <= d2max, everything finite
+        const float oo = sq::dot(o, o), dd = sq::dot(d, d);
+        T.cull = T.safe && finite3(T.nodf) && oo <= S.cull_o2max && dd >= S.cull_d2min && dd <= S.cull_d2max;
+    }
     T.blo = sq::mk(S.root_lo[0], S.root_lo[1], S.root_lo[2]); T.bhi = sq::mk(S.root_hi[0], S.root_hi[1], S.root_hi[2]);
     T.mode = (T.cur & kLeafBit) ? M_LEAF : M_DESCEND;
     if (T.mode == M_DESCEND &&
@@ -478,6 +526,7 @@ __device__ __forceinline__ void trav_begin(Trav& T, const SceneView& S, uint32_t
 template <typename NodeSrc, typename StackT>
 __device__ __forceinline__ void trav_descend(Trav& T, const NodeSrc& N, SQ_LDS StackT* stk, int stride) {
     v4f q0, q1; int ax; uint32_t left, right;
+    const uint32_t parent = T.cur;
     if constexpr (NodeSrc::kBoxInRegisters) {
         const BranchTail B = N.tail(T.cur);
         q0 = v4f{ T.blo.x, T.blo.y, T.blo.z, B.lmax }; q1 = v4f{ T.bhi.x, T.bhi.y, T.bhi.z, B.rmin };
@@ -509,6 +558,11 @@ __device__ __forceinline__ void trav_descend(Trav& T, const NodeSrc& N, SQ_LDS S
     T.cur = went_left ? left : right;
     if constexpr (NodeSrc::kBoxInRegisters) {                           // the chosen child's box (src/BIH.hs:130-141)
         if (went_left) T.bhi = sq::mk(lhx, lhy, lhz); else T.blo = sq::mk(rlx, rly, rlz);
+    }
+    if constexpr (NodeSrc::kCull) {
+        // a child whose culling box the ray misses returns Nothing without being visited (sq_cull_boxes): for a leaf,
+        // mollerTrumbore would reject every triangle (src/BIH.hs:105-109)
+        if (T.cull && N.cull_on && !N.child_hit(parent, went_left, T.cur, T.df, T.nodf)) { T.R.tri = -1; T.mode = M_UNWIND; return; }
     }
     if (T.cur & kLeafBit) T.mode = M_LEAF;
 }
@@ -613,6 +667,9 @@ __device__ __forceinline__ void trav_unwind(Trav& T, const NodeSrc& N, const Tri
     if constexpr (NodeSrc::kBoxInRegisters) {
         if (l2r) { if (ax == 0) T.blo.x = B.rmin; else if (ax == 1) T.blo.y = B.rmin; else T.blo.z = B.rmin; }
         else     { if (ax == 0) T.bhi.x = B.lmax; else if (ax == 1) T.bhi.y = B.lmax; else T.bhi.z = B.lmax; }
+    }
+    if constexpr (NodeSrc::kCull) {
+        if (T.cull && N.cull_on && !N.child_hit(e, !l2r, T.cur, T.df, T.nodf)) { T.R.tri = -1; T.mode = M_UNWIND; return; }   // as in trav_descend
     }
     T.mode = (T.cur & kLeafBit) ? M_LEAF : M_DESCEND;
 }

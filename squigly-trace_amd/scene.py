@@ -109,6 +109,13 @@ class BIH:
     def bounds(self):
         return np.array(list(self.scene.root.lo) + list(self.scene.root.hi), np.float32)
 
+    def cull_boxes(self):
+        """(boxes [n_nodes, 6], (o2max, d2min, d2max)): the culling boxes the device kernels use (sq_cull_boxes)."""
+        boxes = np.empty((self.scene.n_nodes, 6), np.float32)
+        lim = np.empty(3, np.float32)
+        N.check(N.lib().sq_cull_boxes(C.byref(self.scene), boxes.ctypes.data, lim.ctypes.data))
+        return boxes, tuple(float(x) for x in lim)
+
     def __del__(self):
         if getattr(self, "_h", None) and N is not None and N._lib is not None:
             N._lib.sq_bih_free(self._h)

@@ -500,7 +500,8 @@ def test_pooled_and_classic_trace_kernels_agree(sqt, product_scene, oracle_scene
     try:
         for opts in ({"pool": 0}, {"pool": 1, "refill_min": 1, "flush_min": 0}, {"pool": 1, "refill_min": 64, "flush_min": 64},
                      {"pool": 1, "refill_min": 12, "flush_min": 40, "resident": 0}, {"pool": 0, "resident": 0},
-                     {"pool": 1, "resident": 0, "pixel_major": 1}, {"pool": 1, "resident": 1, "pixel_major": 1}):
+                     {"pool": 1, "resident": 0, "pixel_major": 1}, {"pool": 1, "resident": 1, "pixel_major": 1},
+                     {"pool": 1, "resident": 1, "pixel_major": 0, "cull": 0}, {"pool": 0, "resident": 0, "cull": 0}):
             for k, v in opts.items():
                 dev.set_option(k, v)
             avg, rgb = dev.render_rows(cam, n, w, h)
@@ -508,7 +509,7 @@ def test_pooled_and_classic_trace_kernels_agree(sqt, product_scene, oracle_scene
             assert np.array_equal(bits(avg.cpu().numpy()), bits(o)), opts
             assert np.array_equal(rgb.cpu().numpy(), o8), opts
     finally:
-        for k, v in {"pool": 1, "refill_min": 12, "flush_min": 40, "resident": 1, "pixel_major": -1}.items():
+        for k, v in {"pool": 1, "refill_min": 12, "flush_min": 40, "resident": 1, "pixel_major": -1, "cull": 1}.items():
             dev.set_option(k, v)
 
 
@@ -566,3 +567,85 @@ def test_bench_launches_its_own_ranks(sqt):
     assert j1["n_gpus"] == 1 and j2["n_gpus"] == 2 and j2["scaling"] == "strong" and "not_a_measurement" in j2
     assert j2["config"]["samples_per_step"] == j1["config"]["samples_per_step"] == 96 * 64 * 8      # the SAME frame, shared
     assert j2["config"]["nonblack_pixels"] == j1["config"]["nonblack_pixels"] > 0                   # and the same image
+
+
+def test_culling_slab_test_on_the_device_is_the_one_the_lemma_is_about(sqt):
+    """SQ_OP_CULL_SLAB (the trace kernels' culling slab test: v_fma_mix_f32 on packed binary16 planes) against exact rational
+    arithmetic rounded once per plane value: every binary16 value in both halves of a word, infinities and the excluded
+    subnormals included, and random boxes and rays."""
+    from fractions import Fraction
+    from importlib import import_module
+    N = import_module("squigly-trace_amd._native")
+    rng = np.random.default_rng(77)
+    f32 = np.float32
+    # 1. conversion of every binary16 value from either half: box [x, x] x R x R against a ray along +x from x - 1 hits iff x is not NaN
+    halves = np.arange(0x10000, dtype=np.uint32)
+    hv = halves.astype(np.uint16).view(np.float16).astype(np.float64)
+    for pos in (0, 1):
+        a = np.zeros((len(halves), 9), np.uint32)
+        a[:, 0] = (halves | (0x7C00 << 16)) if pos == 0 else ((halves << 16) | 0xFC00)
+        a[:, 1] = a[:, 2] = 0xFC00 | (0x7C00 << 16)
+        ray = np.zeros((len(halves), 6), f32); ray[:, 0] = 0.25; ray[:, 3:] = (1.0, 0.5, 0.5)
+        a[:, 3:] = ray.view(np.uint32)
+        got = N.debug_eval("cull_slab", a)
+        # lo = x (pos 0): the slab is [x, inf): hit iff it reaches t > 0, always unless x = +inf or NaN; hi = x (pos 1): (-inf, x]: hit iff x > 0.25
+        want = (hv < np.inf) if pos == 0 else (hv > 0.25)
+        skip = np.isnan(hv) | ((np.abs(hv) < 2.0 ** -14) & (hv != 0))     # NaN and subnormals: never produced by sq_half_outward
+        assert np.array_equal(got[~skip].astype(bool), want[~skip]), pos
+    # 2. random boxes and rays against exact arithmetic
+    n = 4000
+    L = N.lib()
+    lo = rng.standard_normal((n, 3)) * 2; hi = lo + np.abs(rng.standard_normal((n, 3))) * 10.0 ** rng.uniform(-3, 0.5, (n, 1))
+    o = (rng.standard_normal((n, 3)) * 3).astype(f32)
+    d = rng.standard_normal((n, 3)); d = (d / np.linalg.norm(d, axis=1)[:, None] * rng.uniform(0.6, 1.2, (n, 1))).astype(f32)
+    # aim half of the rays at a box face so that hits and misses are both common and some are close calls
+    tgt = lo + (hi - lo) * rng.random((n, 3)) + rng.standard_normal((n, 3)) * 10.0 ** rng.uniform(-6, -1, (n, 1))
+    aim = rng.random(n) < 0.6
+    dd = (tgt - o); dd = (dd / np.linalg.norm(dd, axis=1)[:, None]).astype(f32)
+    d[aim] = dd[aim]
+    a = np.zeros((n, 9), np.uint32)
+    hb = np.zeros((n, 6))
+    for i in range(n):
+        for c in range(3):
+            l16, h16 = L.sq_half_outward(float(lo[i, c]), 0), L.sq_half_outward(float(hi[i, c]), 1)
+            a[i, c] = l16 | (h16 << 16)
+            hb[i, c] = float(np.array([l16], np.uint16).view(np.float16)[0]); hb[i, 3 + c] = float(np.array([h16], np.uint16).view(np.float16)[0])
+    a[:, 3:6] = o.view(np.uint32); a[:, 6:9] = d.view(np.uint32)
+    got = N.debug_eval("cull_slab", a).astype(bool)
+    with np.errstate(all="ignore"):
+        df = (f32(1) / d); nodf = (-o * df)
+    want = np.zeros(n, bool)
+    for i in range(n):
+        tl = [f32(float(Fraction(hb[i, c]) * Fraction(float(df[i, c])) + Fraction(float(nodf[i, c])))) for c in range(3)]
+        th = [f32(float(Fraction(hb[i, 3 + c]) * Fraction(float(df[i, c])) + Fraction(float(nodf[i, c])))) for c in range(3)]
+        tmin = max(min(x, y) for x, y in zip(tl, th)); tmax = min(max(x, y) for x, y in zip(tl, th))
+        want[i] = tmax > 0 and tmin < tmax
+    assert 0.2 < want.mean() < 0.8
+    assert np.array_equal(got, want), np.flatnonzero(got != want)[:10]
+
+
+def test_leaf_culling_changes_no_bit_and_removes_most_triangle_tests(sqt, product_scene, oracle_scene, dev):
+    """Option `cull` (a ray that misses a leaf's culling box skips the leaf: sq_cull_boxes) against the oracle, which tests every
+    triangle of every leaf the reference visits; with the profile build's counters: the tests it saves."""
+    import torch
+    bih, cam, _ = product_scene
+    ob, ocam, _ = oracle_scene
+    w, h, n = 200, 150, 16
+    o, o8, _ = ob.render(ocam, n, w, h, threads=THREADS)
+    tested = {}
+    try:
+        for cull in (0, 1):
+            for opts in ({"pool": 1, "profile": 1}, {"pool": 0, "profile": 0}, {"pool": 1, "profile": 0, "primary_resident": 0}):
+                for k, v in {**opts, "cull": cull}.items():
+                    dev.set_option(k, v)
+                dev.stats(reset=True)
+                avg, rgb = dev.render_rows(cam, n, w, h)
+                torch.cuda.synchronize()
+                assert np.array_equal(bits(avg.cpu().numpy()), bits(o)), (cull, opts)
+                assert np.array_equal(rgb.cpu().numpy(), o8), (cull, opts)
+                if opts.get("profile"):
+                    tested[cull] = dev.stats()[5]                     # pooled form, profile build: triangle tests run
+    finally:
+        for k, v in {"pool": 1, "profile": 0, "primary_resident": 1, "cull": 1}.items():
+            dev.set_option(k, v)
+    assert tested[0] > 0 and tested[1] < 0.6 * tested[0], tested
