@@ -104,7 +104,7 @@ __global__ void __launch_bounds__(kBlock) sq_render_pixels(const SceneView S, co
     const long long pix = (long long)blockIdx.x * kBlock + threadIdx.x;
     if (pix >= (long long)F.local_rows * F.h) return;
     int y, x; pixel_coords(F, pix, y, x);
-    const GlobalNodes N{ S.branches };
+    const GlobalNodes N{ S.branches, S.cull_child, S.cull_child != nullptr };
     const f3 o0 = sq::mk(F.cam_pos[0], F.cam_pos[1], F.cam_pos[2]);
     const f3 d0 = primary_dir(F.cam_rot, F.w, F.h, y, x);
     const int n = F.samples;
@@ -197,7 +197,7 @@ __global__ void __launch_bounds__(kBlock) sq_primary(const SceneView S, const Fr
     Hit h0; h0.tri = -1; h0.t = 0;
     if (in) {
         int y, x; pixel_coords(F, pix, y, x);
-        const GlobalNodes N{ S.branches };
+        const GlobalNodes N{ S.branches, S.cull_child, S.cull_child != nullptr };
         h0 = trace_one(S, N, sq::mk(F.cam_pos[0], F.cam_pos[1], F.cam_pos[2]), primary_dir(F.cam_rot, F.w, F.h, y, x), stk, kBlock);
     }
     const int a = wave_append(W.n_active, in && h0.tri >= 0);
@@ -521,7 +521,7 @@ __global__ void __launch_bounds__(BLOCK) sq_trace_rays(const SceneView S, const 
         root_ref = S.rroot;
     } else {
         for (int i = threadIdx.x; i < 3 * A.n_lds; i += BLOCK) { const float4 q = S.branches[i]; lquads[i] = v4f{ q.x, q.y, q.z, q.w }; }
-        N = HybridNodes{ lquads, S.branches, (uint32_t)A.n_lds };
+        N = HybridNodes{ lquads, S.branches, (uint32_t)A.n_lds, S.cull_child, S.cull_child != nullptr };
         G = GlobalTris{ S.tris, S.leaves, S.packed_leaves != 0, (size_t)S.n_tris * sizeof(DevTri) > ((size_t)4 << 20) };
         root_ref = S.root_ref;
     }
@@ -876,7 +876,7 @@ __global__ void sq_debug_kernel(int op, const void* a, const void* b, long long 
 struct sq_device_scene {
     int device = 0;
     SceneView view{};
-    void *d_branches = nullptr, *d_leaves = nullptr, *d_tris = nullptr, *d_mats = nullptr, *d_verts = nullptr, *d_trix = nullptr, *d_rbranch = nullptr, *d_emitters = nullptr, *d_tri_mat = nullptr, *d_surfs = nullptr;
+    void *d_branches = nullptr, *d_leaves = nullptr, *d_tris = nullptr, *d_mats = nullptr, *d_verts = nullptr, *d_trix = nullptr, *d_rbranch = nullptr, *d_emitters = nullptr, *d_tri_mat = nullptr, *d_surfs = nullptr, *d_cull_child = nullptr;
     int height = 0; bool small_index = false; int n_cu = 256;
     // workspace (grow-only)
     Work work{}; void* d_work = nullptr; size_t work_bytes = 0; int64_t work_pixels = 0, work_slots = 0;
@@ -1092,6 +1092,18 @@ extern "C" int sq_scene_upload(const sq_scene* sc, int32_t device, sq_device_sce
             rroot = enc(ref[0]);
         } else { trix.clear(); cull_resident = false; }
     }
+    // Streaming forms: the culling boxes of a branch's two children, with the branch (GlobalNodes / HybridNodes)
+    std::vector<float> cull_child;
+    if (cull_limits[0] >= 0.0f && nb > 0) {
+        cull_child.resize((size_t)nb * 16);
+        for (int32_t i = 0; i < n; ++i) {
+            if ((sc->nodes[i].kind & 3) == 3) continue;
+            float* o = &cull_child[(size_t)ref[(size_t)i] * 16];
+            const float* l = &cbox[(size_t)(i + 1) * 6]; const float* r = &cbox[(size_t)sc->nodes[i].link * 6];
+            o[0] = l[0]; o[1] = l[1]; o[2] = l[2]; o[3] = 0; o[4] = l[3]; o[5] = l[4]; o[6] = l[5]; o[7] = 0;
+            o[8] = r[0]; o[9] = r[1]; o[10] = r[2]; o[11] = 0; o[12] = r[3]; o[13] = r[4]; o[14] = r[5]; o[15] = 0;
+        }
+    }
     // Streaming form: leaf references carry (first, count) themselves when they fit, which saves the dependent
     // leaf-table load of every leaf visit.
     bool packed_leaves = sc->n_tris < (1 << 24);
@@ -1141,7 +1153,8 @@ extern "C" int sq_scene_upload(const sq_scene* sc, int32_t device, sq_device_sce
         up(&s->d_tris, tr.data(), tr.size() * sizeof(DevTri)) || up(&s->d_tri_mat, tri_mat.data(), tri_mat.size() * sizeof(int32_t)) || up(&s->d_surfs, sf.data(), sf.size() * sizeof(DevSurf)) || up(&s->d_mats, mt.data(), mt.size() * sizeof(DevMat)) ||
         up(&s->d_verts, uverts.data(), uverts.size() * sizeof(float)) || up(&s->d_trix, trix.data(), trix.size() * sizeof(uint16_t)) ||
         up(&s->d_rbranch, rbranch.data(), rbranch.size() * sizeof(uint32_t)) ||
-        up(&s->d_emitters, emitters.data(), emitters.size() * sizeof(int32_t))) {
+        up(&s->d_emitters, emitters.data(), emitters.size() * sizeof(int32_t)) ||
+        (!cull_child.empty() && up(&s->d_cull_child, cull_child.data(), cull_child.size() * sizeof(float)))) {
         sq_scene_free(s);
         return 1;
     }
@@ -1165,7 +1178,7 @@ extern "C" int sq_scene_upload(const sq_scene* sc, int32_t device, sq_device_sce
     v.rbranch = (const uint32_t*)s->d_rbranch; v.rroot = rroot;
     v.emitters = (const int32_t*)s->d_emitters; v.n_emitters = n_emitters;
     v.cull_o2max = cull_limits[0]; v.cull_d2min = cull_limits[1]; v.cull_d2max = cull_limits[2];
-    v.cull_resident = cull_resident ? 1 : 0; v.cull_child = nullptr;
+    v.cull_resident = cull_resident ? 1 : 0; v.cull_child = (const float4*)s->d_cull_child;
     *out = s;
     return 0;
 }
@@ -1206,7 +1219,7 @@ extern "C" void sq_scene_free(sq_device_scene* s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
     for (auto& p : s->pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
-    (void)hipFree(s->d_branches); (void)hipFree(s->d_leaves); (void)hipFree(s->d_tris); (void)hipFree(s->d_mats); (void)hipFree(s->d_verts); (void)hipFree(s->d_trix); (void)hipFree(s->d_rbranch); (void)hipFree(s->d_emitters); (void)hipFree(s->d_tri_mat); (void)hipFree(s->d_surfs);
+    (void)hipFree(s->d_branches); (void)hipFree(s->d_leaves); (void)hipFree(s->d_tris); (void)hipFree(s->d_mats); (void)hipFree(s->d_verts); (void)hipFree(s->d_trix); (void)hipFree(s->d_rbranch); (void)hipFree(s->d_emitters); (void)hipFree(s->d_tri_mat); (void)hipFree(s->d_surfs); (void)hipFree(s->d_cull_child);
     if (s->d_work) cache_give(s->device, s->d_work, s->work_bytes);
     for (hipEvent_t e : s->events) (void)hipEventDestroy(e);
     if (s->aux) (void)hipStreamDestroy(s->aux);

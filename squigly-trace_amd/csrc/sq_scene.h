@@ -67,7 +67,7 @@ struct SceneView {
     // skips the leaf's triangles -- mollerTrumbore would reject them all.  cull_o2max < 0: nothing is culled.
     float cull_o2max, cull_d2min, cull_d2max;
     int32_t cull_resident;    // 1: resident leaf references carry a box slot (bits 23..13) and the boxes sit in the vertices' w words
-    const float* cull_child;  // streaming form: 12 floats per branch, the culling boxes of its left and right child; or nullptr
+    const float4* cull_child; // streaming form: 4 quads per branch, the culling boxes (lo, hi) of its left and of its right child; or nullptr
 };
 
 struct Hit { float t; int32_t tri; };   // tri < 0 : Nothing.  dist is derived from t on demand (hit_dist)
@@ -299,10 +299,21 @@ __device__ __forceinline__ BranchData unpack_branch(v4f q0, v4f q1, v4f q2) {
     const BranchTail t = unpack_tail(q2);
     return BranchData{ q0, q1, t.axis, t.left, t.right };
 }
+// Culling boxes of the streaming forms: the box of a CHILD sits with its parent (4 quads per branch: left lo, left hi, right
+// lo, right hi), so that a child -- leaf or branch, whose box is the union of its subtree's -- is tested before anything of
+// its own is read.  fp32: a 1M-triangle scene's leaves are too small for binary16 planes.
+__device__ __forceinline__ bool cull_child_hit(const float4* cull, uint32_t parent, bool is_left, f3 df, f3 nodf) {
+    const float4* p = cull + 4 * (size_t)parent + (is_left ? 0 : 2);
+    const float4 lo = p[0], hi = p[1];
+    const float b[6] = { lo.x, lo.y, lo.z, hi.x, hi.y, hi.z };
+    return cull_slab(b, df, nodf);
+}
 struct GlobalNodes {            // every branch read from HBM/L2
     static constexpr bool kBoxInRegisters = false;
-    static constexpr bool kCull = false;
+    static constexpr bool kCull = true;
     const float4* g;
+    const float4* cull; bool cull_on;
+    __device__ __forceinline__ bool child_hit(uint32_t parent, bool is_left, uint32_t, f3 df, f3 nodf) const { return cull_child_hit(cull, parent, is_left, df, nodf); }
     __device__ __forceinline__ BranchData load(uint32_t b) const {
         const float4 a = g[3 * b], c = g[3 * b + 1], d = g[3 * b + 2];
         return unpack_branch(v4f{ a.x, a.y, a.z, a.w }, v4f{ c.x, c.y, c.z, c.w }, v4f{ d.x, d.y, d.z, d.w });
@@ -324,8 +335,10 @@ struct HybridNodes {            // first n_lds branches (top of the tree) in LDS
 #define SQ_BOX_IN_REGISTERS 0
 #endif
     static constexpr bool kBoxInRegisters = SQ_BOX_IN_REGISTERS != 0;
-    static constexpr bool kCull = false;
+    static constexpr bool kCull = true;
     const SQ_LDS v4f* l; const float4* g; uint32_t n_lds;
+    const float4* cull; bool cull_on;
+    __device__ __forceinline__ bool child_hit(uint32_t parent, bool is_left, uint32_t, f3 df, f3 nodf) const { return cull_child_hit(cull, parent, is_left, df, nodf); }
     __device__ __forceinline__ BranchData load(uint32_t b) const {
         if (b < n_lds) return unpack_branch(l[3 * b], l[3 * b + 1], l[3 * b + 2]);
         const float4 a = g[3 * b], c = g[3 * b + 1], d = g[3 * b + 2];
