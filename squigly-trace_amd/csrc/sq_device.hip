@@ -469,8 +469,8 @@ __device__ __forceinline__ void stage_resident_scene(const SceneView& S, int n_b
         lt[i] = v4us{ (unsigned short)(t.x * 16u), (unsigned short)(t.y * 16u), (unsigned short)(t.z * 16u), t.w };
     }
     if (threadIdx.x < ResidentTris::kRunPad) lt[S.n_tris + threadIdx.x] = v4us{ 0, 0, 0, 0 };
-    N = ResidentNodes{ lquads, lquads + n_branches, lrefs, S.cull_resident != 0 };
-    G = ResidentTris{ lt, S.cull_resident ? ResidentNodes::kFirstMask : 0xFFFFFFu };
+    N = ResidentNodes{ lquads, lquads + n_branches, lrefs, S.cull_child16 != nullptr, S.cull_child16, S.rtail };
+    G = ResidentTris{ lt };
     if ((uintptr_t)lv != 0) __builtin_trap();                              // the kernels that use this have no static LDS: dynamic LDS starts at address 0
 }
 
@@ -876,7 +876,7 @@ __global__ void sq_debug_kernel(int op, const void* a, const void* b, long long 
 struct sq_device_scene {
     int device = 0;
     SceneView view{};
-    void *d_branches = nullptr, *d_leaves = nullptr, *d_tris = nullptr, *d_mats = nullptr, *d_verts = nullptr, *d_trix = nullptr, *d_rbranch = nullptr, *d_emitters = nullptr, *d_tri_mat = nullptr, *d_surfs = nullptr, *d_cull_child = nullptr;
+    void *d_branches = nullptr, *d_leaves = nullptr, *d_tris = nullptr, *d_mats = nullptr, *d_verts = nullptr, *d_trix = nullptr, *d_rbranch = nullptr, *d_emitters = nullptr, *d_tri_mat = nullptr, *d_surfs = nullptr, *d_cull_child = nullptr, *d_cull16 = nullptr, *d_rtail = nullptr;
     int height = 0; bool small_index = false; int n_cu = 256;
     // workspace (grow-only)
     Work work{}; void* d_work = nullptr; size_t work_bytes = 0; int64_t work_pixels = 0, work_slots = 0;
@@ -1058,28 +1058,14 @@ extern "C" int sq_scene_upload(const sq_scene* sc, int32_t device, sq_device_sce
     std::vector<float> cbox((size_t)n * 6); float cull_limits[3] = { -1.0f, 0.25f, 1.5624f };
     if (sq_cull_boxes(sc, cbox.data(), cull_limits)) return 1;
     // Resident encoding of the branches (see sq_scene.h): needs encodable leaves and a 24-bit index space.
-    std::vector<uint32_t> rbranch; uint32_t rroot = 0; bool cull_resident = false;
+    std::vector<uint32_t> rbranch; uint32_t rroot = 0;
     {
         bool ok = !trix.empty() && nb < (1 << 24) && sc->n_tris < (1 << 24);
         for (int32_t i = 0; i < nl && ok; ++i) ok = lf[(size_t)i].count <= 31;
-        // Leaf culling in the resident form: leaf k's box as six binary16 values (rounded outwards, never subnormal) in the w
-        // words of vertices 3k..3k+2, its slot k in bits 23..13 of the leaf reference (ResidentNodes::child_hit).
-        cull_resident = ok && cull_limits[0] >= 0.0f && sc->n_tris <= (int32_t)ResidentNodes::kFirstMask + 1 &&
-                        nl <= (int32_t)ResidentNodes::kSlotMask + 1 && (size_t)3 * (size_t)nl <= uverts.size() / 4;
-        if (cull_resident) {
-            for (int32_t i = 0; i < n; ++i) {
-                if ((sc->nodes[i].kind & 3) != 3) continue;
-                const uint32_t k = ref[(size_t)i] & ~kLeafBit; const float* b = &cbox[(size_t)i * 6];
-                for (int c = 0; c < 3; ++c) {
-                    const uint32_t w = sq_half_outward(b[c], 0) | (sq_half_outward(b[3 + c], 1) << 16);
-                    std::memcpy(&uverts[((size_t)3 * k + (size_t)c) * 4 + 3], &w, 4);
-                }
-            }
-        }
         auto enc = [&](uint32_t r) -> uint32_t {
             if (!(r & kLeafBit)) return r;
             const DevLeaf& L = lf[r & ~kLeafBit];
-            return kLeafBit | ((uint32_t)L.count << 24) | (cull_resident ? ((r & ~kLeafBit) << ResidentNodes::kSlotShift) : 0u) | (uint32_t)L.first;
+            return kLeafBit | ((uint32_t)L.count << 24) | (uint32_t)L.first;
         };
         if (ok) {
             rbranch.resize((size_t)nb * 10);
@@ -1090,7 +1076,7 @@ extern "C" int sq_scene_upload(const sq_scene* sc, int32_t device, sq_device_sce
                 r[8] = enc(d.left) | ((uint32_t)br_axis[(size_t)i] << 29); r[9] = enc(d.right);
             }
             rroot = enc(ref[0]);
-        } else { trix.clear(); cull_resident = false; }
+        } else { trix.clear(); }
     }
     // Streaming forms: the culling boxes of a branch's two children, with the branch (GlobalNodes / HybridNodes)
     std::vector<float> cull_child;
@@ -1102,6 +1088,16 @@ extern "C" int sq_scene_upload(const sq_scene* sc, int32_t device, sq_device_sce
             const float* l = &cbox[(size_t)(i + 1) * 6]; const float* r = &cbox[(size_t)sc->nodes[i].link * 6];
             o[0] = l[0]; o[1] = l[1]; o[2] = l[2]; o[3] = 0; o[4] = l[3]; o[5] = l[4]; o[6] = l[5]; o[7] = 0;
             o[8] = r[0]; o[9] = r[1]; o[10] = r[2]; o[11] = 0; o[12] = r[3]; o[13] = r[4]; o[14] = r[5]; o[15] = 0;
+        }
+    }
+    std::vector<uint32_t> rtail;                                      // resident form: a return's data per branch, one quad
+    for (size_t b = 0; b * 10 < rbranch.size(); ++b) { const uint32_t* r = &rbranch[b * 10]; rtail.insert(rtail.end(), { r[3], r[7], r[8], r[9] }); }
+    std::vector<uint32_t> cull16;                                     // the same boxes as binary16 pairs, for the resident form
+    if (!trix.empty() && !cull_child.empty()) {
+        cull16.resize((size_t)nb * 8, 0u);
+        for (int32_t b = 0; b < nb; ++b) for (int side = 0; side < 2; ++side) {
+            const float* bx = &cull_child[(size_t)b * 16 + (size_t)side * 8];
+            for (int c = 0; c < 3; ++c) cull16[(size_t)b * 8 + (size_t)side * 4 + (size_t)c] = sq_half_outward(bx[c], 0) | (sq_half_outward(bx[4 + c], 1) << 16);
         }
     }
     // Streaming form: leaf references carry (first, count) themselves when they fit, which saves the dependent
@@ -1154,7 +1150,9 @@ extern "C" int sq_scene_upload(const sq_scene* sc, int32_t device, sq_device_sce
         up(&s->d_verts, uverts.data(), uverts.size() * sizeof(float)) || up(&s->d_trix, trix.data(), trix.size() * sizeof(uint16_t)) ||
         up(&s->d_rbranch, rbranch.data(), rbranch.size() * sizeof(uint32_t)) ||
         up(&s->d_emitters, emitters.data(), emitters.size() * sizeof(int32_t)) ||
-        (!cull_child.empty() && up(&s->d_cull_child, cull_child.data(), cull_child.size() * sizeof(float)))) {
+        (!cull_child.empty() && up(&s->d_cull_child, cull_child.data(), cull_child.size() * sizeof(float))) ||
+        (!cull16.empty() && up(&s->d_cull16, cull16.data(), cull16.size() * sizeof(uint32_t))) ||
+        up(&s->d_rtail, rtail.data(), rtail.size() * sizeof(uint32_t))) {
         sq_scene_free(s);
         return 1;
     }
@@ -1178,7 +1176,7 @@ extern "C" int sq_scene_upload(const sq_scene* sc, int32_t device, sq_device_sce
     v.rbranch = (const uint32_t*)s->d_rbranch; v.rroot = rroot;
     v.emitters = (const int32_t*)s->d_emitters; v.n_emitters = n_emitters;
     v.cull_o2max = cull_limits[0]; v.cull_d2min = cull_limits[1]; v.cull_d2max = cull_limits[2];
-    v.cull_resident = cull_resident ? 1 : 0; v.cull_child = (const float4*)s->d_cull_child;
+    v.cull_child = (const float4*)s->d_cull_child; v.cull_child16 = (const uint4*)s->d_cull16; v.rtail = (const uint4*)s->d_rtail;
     *out = s;
     return 0;
 }
@@ -1219,7 +1217,7 @@ extern "C" void sq_scene_free(sq_device_scene* s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
     for (auto& p : s->pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
-    (void)hipFree(s->d_branches); (void)hipFree(s->d_leaves); (void)hipFree(s->d_tris); (void)hipFree(s->d_mats); (void)hipFree(s->d_verts); (void)hipFree(s->d_trix); (void)hipFree(s->d_rbranch); (void)hipFree(s->d_emitters); (void)hipFree(s->d_tri_mat); (void)hipFree(s->d_surfs); (void)hipFree(s->d_cull_child);
+    (void)hipFree(s->d_branches); (void)hipFree(s->d_leaves); (void)hipFree(s->d_tris); (void)hipFree(s->d_mats); (void)hipFree(s->d_verts); (void)hipFree(s->d_trix); (void)hipFree(s->d_rbranch); (void)hipFree(s->d_emitters); (void)hipFree(s->d_tri_mat); (void)hipFree(s->d_surfs); (void)hipFree(s->d_cull_child); (void)hipFree(s->d_cull16); (void)hipFree(s->d_rtail);
     if (s->d_work) cache_give(s->device, s->d_work, s->work_bytes);
     for (hipEvent_t e : s->events) (void)hipEventDestroy(e);
     if (s->aux) (void)hipStreamDestroy(s->aux);

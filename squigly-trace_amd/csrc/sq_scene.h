@@ -66,8 +66,9 @@ struct SceneView {
     // Leaf culling (sq_cull_boxes, include/squigly_host.h): a ray inside these limits that misses a leaf's culling box
     // skips the leaf's triangles -- mollerTrumbore would reject them all.  cull_o2max < 0: nothing is culled.
     float cull_o2max, cull_d2min, cull_d2max;
-    int32_t cull_resident;    // 1: resident leaf references carry a box slot (bits 23..13) and the boxes sit in the vertices' w words
     const float4* cull_child; // streaming form: 4 quads per branch, the culling boxes (lo, hi) of its left and of its right child; or nullptr
+    const uint4* rtail;       // resident form: (lmax, rmin, left word, right word) per branch, what a return into a branch needs
+    const uint4* cull_child16; // resident form: 2 quads per branch, the same boxes as binary16 pairs (x, y, z, unused), left child then right; or nullptr
 };
 
 struct Hit { float t; int32_t tri; };   // tri < 0 : Nothing.  dist is derived from t on demand (hit_dist)
@@ -359,17 +360,16 @@ struct ResidentNodes {
     // (lo, lmax) of all branches, then (hi, rmin) of all branches: a wave's read of either spreads over all 16 bank slots
     const SQ_LDS v4f* quads; const SQ_LDS v4f* quads_hi;
     const SQ_LDS v2i* refs;       // 1 per branch
-    // Leaf culling: with cull_on a leaf reference carries a box slot in bits 23..13 and the first triangle in bits 12..0.
-    // Slot k's box is six binary16 values in the otherwise unused w words of vertices 3k, 3k+1, 3k+2 (the vertex table
-    // starts at LDS address 0): lo.x | hi.x << 16, then y, then z.  The scene's 127 KB leave no room for a table of its own.
+    // Culling boxes (sq_cull_boxes) of a branch's two children -- leaves and whole subtrees -- as binary16 pairs, two quads
+    // per branch in GLOBAL memory (20 KB for scene.obj: L1-resident).  The LDS has no room for them, and more to the point
+    // the kernel is held by the CU's LDS pipe while its vector-memory path idles: the same boxes in the vertices' unused w
+    // words cost 70.0 ms per headline frame against 62.5 ms from global memory (same run).
     static constexpr bool kCull = true;
-    static constexpr uint32_t kSlotShift = 13, kSlotMask = 0x7FFu, kFirstMask = 0x1FFFu;
     bool cull_on;
-    __device__ __forceinline__ bool child_hit(uint32_t, bool, uint32_t ref, f3 df, f3 nodf) const {
-        if (!(ref & kLeafBit)) return true;                              // only leaves have boxes here
-        const uint32_t slot = (ref >> kSlotShift) & kSlotMask;
-        const SQ_LDS uint32_t* p = reinterpret_cast<const SQ_LDS uint32_t*>((uintptr_t)(slot * 48u + 12u));
-        return cull_slab_half(p[0], p[4], p[8], df, nodf);
+    const uint4* cull16;
+    __device__ __forceinline__ bool child_hit(uint32_t parent, bool is_left, uint32_t, f3 df, f3 nodf) const {
+        const uint4 w = cull16[2 * parent + (is_left ? 0u : 1u)];
+        return cull_slab_half(w.x, w.y, w.z, df, nodf);
     }
     __device__ __forceinline__ v4f q0(uint32_t b) const { return quads[b]; }
     __device__ __forceinline__ v4f q1(uint32_t b) const { return quads_hi[b]; }
@@ -377,7 +377,15 @@ struct ResidentNodes {
         const v2i r = refs[b];
         return BranchData{ q0(b), q1(b), (int)(((uint32_t)r.x >> 29) & 3u), (uint32_t)r.x & ~kResAxisMask, (uint32_t)r.y };
     }
+#ifndef SQ_RES_TAIL_GLOBAL
+#define SQ_RES_TAIL_GLOBAL 0      // measured: 64.2 ms per headline frame with the global tail against 62.5 ms with the three LDS reads (same run)
+#endif
+    const uint4* rtail;           // global copy of (lmax, rmin, left word, right word) per branch: what a return needs, in one load
     __device__ __forceinline__ BranchTail tail(uint32_t b) const {
+        if (SQ_RES_TAIL_GLOBAL) {   // one global load (10 KB table, L1) instead of three LDS reads: the LDS pipe is what binds
+            const uint4 t = rtail[b];
+            return BranchTail{ __uint_as_float(t.x), __uint_as_float(t.y), (int)((t.z >> 29) & 3u), t.z & ~kResAxisMask, t.w };
+        }
         const v2i r = refs[b];
         return BranchTail{ q0(b).w, q1(b).w, (int)(((uint32_t)r.x >> 29) & 3u), (uint32_t)r.x & ~kResAxisMask, (uint32_t)r.y };
     }
@@ -431,7 +439,6 @@ struct ResidentTris {           // whole scene resident in LDS: 16-bit indexed t
     // vertex address is the record field itself, no shift and no base add (integer VALU ops cost 4.2 cycles here
     // against 2.5 for an fp32 multiply, tools/ubench/op_rate.hip).
     const SQ_LDS v4us* trix;
-    uint32_t first_mask;      // bits of a leaf reference that hold its first triangle (the rest of bits 23..0 is a culling-box slot)
     __device__ __forceinline__ v4f vertex(unsigned off) const { return *reinterpret_cast<const SQ_LDS v4f*>((uintptr_t)off); }   // LDS address = offset (table at LDS address 0)
     __device__ __forceinline__ void get(int i, f3& v0, f3& e1, f3& e2) const { get_indexed(trix[i], v0, e1, e2); }
     __device__ __forceinline__ void get1(int i, f3& v0, f3& e1, f3& e2) const {    // three 16-bit reads: the offsets arrive zero-extended
@@ -466,7 +473,7 @@ struct ResidentTris {           // whole scene resident in LDS: 16-bit indexed t
         e1 = sq::mk(b.x, b.y, b.z) - v0;
         e2 = sq::mk(c.x, c.y, c.z) - v0;
     }
-    __device__ __forceinline__ int2 leaf(uint32_t ref) const { return make_int2((int)(ref & first_mask), (int)((ref >> 24) & 31u)); }
+    __device__ __forceinline__ int2 leaf(uint32_t ref) const { return make_int2((int)(ref & 0xFFFFFFu), (int)((ref >> 24) & 31u)); }
 };
 
 // ---- wave64 prefix scans on the DPP network (gfx9 DPP: row_shr inside rows of 16 lanes, then row_bcast:15 and

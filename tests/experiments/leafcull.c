@@ -12,7 +12,7 @@ static void ray_hook(const void* b, float ox, float oy, float oz, float dx, floa
 static float g_margin = 1e-3f;
 typedef struct { sqo_bounds box; int ready; } tbox;
 static tbox* g_leafbox;      /* by node->first for leaves */
-typedef struct nbox { const node* nd; sqo_bounds box; } nbox;
+typedef struct nbox { const node* nd; sqo_bounds box; int depth, pre, bfs; } nbox;
 static nbox* g_nb; static int g_nnb;
 
 static sqo_bounds tri_bounds(const node* nd) {
@@ -55,8 +55,9 @@ static float half_down(float x) {   /* largest fp16 value <= x (binary search ov
 }
 static float half_up(float x) { return -half_down(-x); }
 static int g_half = 0;
+static int g_depth_now = 0;
 static void collect(const node* nd) {
-    g_nb[g_nnb].nd = nd; g_nb[g_nnb].box = tri_bounds(nd);
+    g_nb[g_nnb].nd = nd; g_nb[g_nnb].depth = g_depth_now; g_nb[g_nnb].pre = g_nnb; g_nb[g_nnb].box = tri_bounds(nd);
     sqo_bounds* b = &g_nb[g_nnb].box; float m = g_margin;
     if (g_margin < 0) {          /* worst-case margin: 64 (u/eps) P (S + E1 + E2), S = -g_margin, over the subtree's triangles */
         m = subtree_margin(nd, -g_margin);
@@ -64,7 +65,7 @@ static void collect(const node* nd) {
     b->lo.x -= m; b->lo.y -= m; b->lo.z -= m; b->hi.x += m; b->hi.y += m; b->hi.z += m;
     if (g_half) { b->lo.x = half_down(b->lo.x); b->lo.y = half_down(b->lo.y); b->lo.z = half_down(b->lo.z); b->hi.x = half_up(b->hi.x); b->hi.y = half_up(b->hi.y); b->hi.z = half_up(b->hi.z); }
     g_nnb++;
-    if (nd->kind != 3) { collect(nd->l); collect(nd->r); }
+    if (nd->kind != 3) { g_depth_now++; collect(nd->l); collect(nd->r); g_depth_now--; }
 }
 static const sqo_bounds* box_of(const node* nd) {   /* small tree: linear probe is fine for scene.obj, hash by pointer otherwise */
     static const node* last; static const sqo_bounds* lastb;
@@ -78,16 +79,18 @@ typedef struct { const node* k; int v; } slot;
 static slot* g_tab; static size_t g_tabn;
 static void tab_build(void) { g_tabn = 1; while (g_tabn < (size_t)g_nnb * 4) g_tabn <<= 1; g_tab = calloc(g_tabn, sizeof *g_tab);
     for (int i = 0; i < g_nnb; i++) { size_t h = ((uintptr_t)g_nb[i].nd >> 4) * 2654435761u & (g_tabn - 1); while (g_tab[h].k) h = (h + 1) & (g_tabn - 1); g_tab[h].k = g_nb[i].nd; g_tab[h].v = i; } }
+static int g_b0 = 0;
+static int bfs_of(const node* nd) { size_t h = ((uintptr_t)nd >> 4) * 2654435761u & (g_tabn - 1); while (g_tab[h].k != nd) h = (h + 1) & (g_tabn - 1); return g_nb[g_tab[h].v].bfs; }
 static const sqo_bounds* box_fast(const node* nd) { size_t h = ((uintptr_t)nd >> 4) * 2654435761u & (g_tabn - 1); while (g_tab[h].k != nd) h = (h + 1) & (g_tabn - 1); return &g_nb[g_tab[h].v].box; }
 
 typedef struct { uint64_t rays, leaf, tri, branch, leaf_culled, sub_culled, mism; } stats;
-static __thread stats S[3];
-static stats G[3]; static pthread_mutex_t gmu = PTHREAD_MUTEX_INITIALIZER;
+static __thread stats S[4];
+static stats G[4]; static pthread_mutex_t gmu = PTHREAD_MUTEX_INITIALIZER;
 
 /* variant 1: cull leaves by their tight box; variant 2: cull every child (leaf or branch) by its tight box */
 static sqo_hit rec(int variant, sqo_bounds bbox, const node* nd, V3 o, V3 d, stats* s) {
     sqo_hit none; memset(&none, 0, sizeof none); none.tri = -1;
-    if (variant >= 1 && (nd->kind == 3 || variant == 2)) {
+    if (variant >= 1 && (nd->kind == 3 || variant == 2 || (variant == 3 && bfs_of(nd) >= g_b0))) {
         if (!sqo_intersects_bb(box_fast(nd), o, d)) { if (nd->kind == 3) s->leaf_culled++; else s->sub_culled++; return none; }
     }
     if (nd->kind == 3) {
@@ -121,12 +124,12 @@ static sqo_hit rec(int variant, sqo_bounds bbox, const node* nd, V3 o, V3 d, sta
 }
 static void ray_hook(const void* bv, float ox, float oy, float oz, float dx, float dy, float dz, const void* outv) {
     const sqo_bih* b = bv; const sqo_hit* ref = outv; V3 o = v3(ox, oy, oz), d = v3(dx, dy, dz);
-    for (int v = 0; v < 3; v++) {
+    for (int v = 0; v < 4; v++) {
         S[v].rays++;
         sqo_hit h = rec(v, b->bounds, b->tree, o, d, &S[v]);
         if (h.hit != ref->hit || (h.hit && (h.tri != ref->tri || memcmp(&h.dist, &ref->dist, 4)))) S[v].mism++;
     }
-    if (S[0].rays % 4096 == 0) { pthread_mutex_lock(&gmu); for (int v = 0; v < 3; v++) { uint64_t* a = (uint64_t*)&G[v]; uint64_t* t = (uint64_t*)&S[v]; for (int k = 0; k < 7; k++) { a[k] += t[k]; t[k] = 0; } } pthread_mutex_unlock(&gmu); }
+    if (S[0].rays % 4096 == 0) { pthread_mutex_lock(&gmu); for (int v = 0; v < 4; v++) { uint64_t* a = (uint64_t*)&G[v]; uint64_t* t = (uint64_t*)&S[v]; for (int k = 0; k < 7; k++) { a[k] += t[k]; t[k] = 0; } } pthread_mutex_unlock(&gmu); }
 }
 int main(int argc, char** argv) {
     int spp = argc > 1 ? atoi(argv[1]) : 16, step = argc > 2 ? atoi(argv[2]) : 40; if (argc > 3) g_margin = (float)atof(argv[3]);
@@ -137,12 +140,17 @@ int main(int argc, char** argv) {
     if (sqo_tris_from_obj(obj, dir, &tris, &n)) { fprintf(stderr, "%s\n", sqo_last_error()); return 1; }
     sqo_bih* b = sqo_make_bih(tris, n);
     { sqo_bounds rb = tri_bounds(b->tree); double vx = fmax(fabs(rb.lo.x), fabs(rb.hi.x)), vy = fmax(fabs(rb.lo.y), fabs(rb.hi.y)), vz = fmax(fabs(rb.lo.z), fabs(rb.hi.z)); g_omax2 = 2 * sqrt(vx*vx+vy*vy+vz*vz); g_half = getenv("HALF") != 0; printf("omax2 %g half %d\n", g_omax2, g_half); }
-    g_nb = malloc(sizeof(nbox) * (size_t)(2 * b->n_nodes + 4)); collect(b->tree); tab_build();
+    g_nb = malloc(sizeof(nbox) * (size_t)(2 * b->n_nodes + 4)); collect(b->tree);
+    { int nbr = 0, maxd = 0; for (int i = 0; i < g_nnb; i++) if (g_nb[i].depth > maxd) maxd = g_nb[i].depth;
+      for (int dd = 0; dd <= maxd; dd++) for (int i = 0; i < g_nnb; i++) if (g_nb[i].nd->kind != 3 && g_nb[i].depth == dd) g_nb[i].bfs = nbr++;
+      for (int i = 0; i < g_nnb; i++) if (g_nb[i].nd->kind == 3) g_nb[i].bfs = 1 << 30;
+      g_b0 = getenv("B0") ? atoi(getenv("B0")) : 209; printf("branches %d, b0 %d\n", nbr, g_b0); }
+    tab_build();
     sqo_camera cam; sqo_load_camera(camf, 0, &cam);
     sqo_counters c;
     sqo_render_rows_strided(b, &cam, spp, w, h, 0, step / 2, w, step, 8, 0, 0, 0, 0, &c);
-    const char* names[3] = { "reference", "leaf boxes", "leaf+subtree boxes" };
-    for (int v = 0; v < 3; v++) { stats* s = &G[v];
+    const char* names[4] = { "reference", "leaf boxes", "leaf+subtree boxes", "leaf+deep subtrees" };
+    for (int v = 0; v < 4; v++) { stats* s = &G[v];
         printf("%-20s rays %llu  per ray: branch %.2f leaf %.2f tri %.2f  culled leaves %.2f subtrees %.2f  mismatches %llu\n", names[v],
                (unsigned long long)s->rays, (double)s->branch / s->rays, (double)s->leaf / s->rays, (double)s->tri / s->rays,
                (double)s->leaf_culled / s->rays, (double)s->sub_culled / s->rays, (unsigned long long)s->mism); }

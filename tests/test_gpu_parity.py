@@ -635,7 +635,7 @@ def test_leaf_culling_changes_no_bit_and_removes_most_triangle_tests(sqt, produc
     tested = {}
     try:
         for cull in (0, 1):
-            for opts in ({"pool": 1, "profile": 1}, {"pool": 0, "profile": 0}, {"pool": 1, "profile": 0, "primary_resident": 0}):
+            for opts in ({"pool": 1, "profile": 1}, {"pool": 0, "profile": 0}, {"pool": 1, "profile": 0, "primary_resident": 0}, {"pool": 1, "profile": 0, "resident": 0}):
                 for k, v in {**opts, "cull": cull}.items():
                     dev.set_option(k, v)
                 dev.stats(reset=True)
@@ -646,6 +646,6 @@ def test_leaf_culling_changes_no_bit_and_removes_most_triangle_tests(sqt, produc
                 if opts.get("profile"):
                     tested[cull] = dev.stats()[5]                     # pooled form, profile build: triangle tests run
     finally:
-        for k, v in {"pool": 1, "profile": 0, "primary_resident": 1, "cull": 1}.items():
+        for k, v in {"pool": 1, "profile": 0, "primary_resident": 1, "cull": 1, "resident": 1}.items():
             dev.set_option(k, v)
     assert tested[0] > 0 and tested[1] < 0.6 * tested[0], tested
