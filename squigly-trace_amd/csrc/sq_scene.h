@@ -303,9 +303,13 @@ __device__ __forceinline__ BranchData unpack_branch(v4f q0, v4f q1, v4f q2) {
 // Culling boxes of the streaming forms: the box of a CHILD sits with its parent (4 quads per branch: left lo, left hi, right
 // lo, right hi), so that a child -- leaf or branch, whose box is the union of its subtree's -- is tested before anything of
 // its own is read.  fp32: a 1M-triangle scene's leaves are too small for binary16 planes.
-__device__ __forceinline__ bool cull_child_hit(const float4* cull, uint32_t parent, bool is_left, f3 df, f3 nodf) {
-    const float4* p = cull + 4 * (size_t)parent + (is_left ? 0 : 2);
-    const float4 lo = p[0], hi = p[1];
+struct CullBoxes32 { float4 llo, lhi, rlo, rhi; };
+__device__ __forceinline__ CullBoxes32 cull_load32(const float4* cull, uint32_t parent) {
+    const float4* p = cull + 4 * (size_t)parent;
+    return CullBoxes32{ p[0], p[1], p[2], p[3] };
+}
+__device__ __forceinline__ bool cull_test32(const CullBoxes32& c, bool left, f3 df, f3 nodf) {
+    const float4 lo = left ? c.llo : c.rlo, hi = left ? c.lhi : c.rhi;
     const float b[6] = { lo.x, lo.y, lo.z, hi.x, hi.y, hi.z };
     return cull_slab(b, df, nodf);
 }
@@ -314,7 +318,9 @@ struct GlobalNodes {            // every branch read from HBM/L2
     static constexpr bool kCull = true;
     const float4* g;
     const float4* cull; bool cull_on;
-    __device__ __forceinline__ bool child_hit(uint32_t parent, bool is_left, uint32_t, f3 df, f3 nodf) const { return cull_child_hit(cull, parent, is_left, df, nodf); }
+    using CullBoxes = CullBoxes32;
+    __device__ __forceinline__ CullBoxes cull_load(uint32_t parent) const { return cull_load32(cull, parent); }
+    __device__ __forceinline__ bool cull_test(const CullBoxes& c, bool left, f3 df, f3 nodf) const { return cull_test32(c, left, df, nodf); }
     __device__ __forceinline__ BranchData load(uint32_t b) const {
         const float4 a = g[3 * b], c = g[3 * b + 1], d = g[3 * b + 2];
         return unpack_branch(v4f{ a.x, a.y, a.z, a.w }, v4f{ c.x, c.y, c.z, c.w }, v4f{ d.x, d.y, d.z, d.w });
@@ -339,7 +345,9 @@ struct HybridNodes {            // first n_lds branches (top of the tree) in LDS
     static constexpr bool kCull = true;
     const SQ_LDS v4f* l; const float4* g; uint32_t n_lds;
     const float4* cull; bool cull_on;
-    __device__ __forceinline__ bool child_hit(uint32_t parent, bool is_left, uint32_t, f3 df, f3 nodf) const { return cull_child_hit(cull, parent, is_left, df, nodf); }
+    using CullBoxes = CullBoxes32;
+    __device__ __forceinline__ CullBoxes cull_load(uint32_t parent) const { return cull_load32(cull, parent); }
+    __device__ __forceinline__ bool cull_test(const CullBoxes& c, bool left, f3 df, f3 nodf) const { return cull_test32(c, left, df, nodf); }
     __device__ __forceinline__ BranchData load(uint32_t b) const {
         if (b < n_lds) return unpack_branch(l[3 * b], l[3 * b + 1], l[3 * b + 2]);
         const float4 a = g[3 * b], c = g[3 * b + 1], d = g[3 * b + 2];
@@ -367,8 +375,10 @@ struct ResidentNodes {
     static constexpr bool kCull = true;
     bool cull_on;
     const uint4* cull16;
-    __device__ __forceinline__ bool child_hit(uint32_t parent, bool is_left, uint32_t, f3 df, f3 nodf) const {
-        const uint4 w = cull16[2 * parent + (is_left ? 0u : 1u)];
+    struct CullBoxes { uint4 l, r; };
+    __device__ __forceinline__ CullBoxes cull_load(uint32_t parent) const { return CullBoxes{ cull16[2 * parent], cull16[2 * parent + 1] }; }
+    __device__ __forceinline__ bool cull_test(const CullBoxes& c, bool left, f3 df, f3 nodf) const {
+        const uint4 w = left ? c.l : c.r;
         return cull_slab_half(w.x, w.y, w.z, df, nodf);
     }
     __device__ __forceinline__ v4f q0(uint32_t b) const { return quads[b]; }
@@ -546,7 +556,12 @@ __device__ __forceinline__ void trav_begin(Trav& T, const SceneView& S, uint32_t
 template <typename NodeSrc, typename StackT>
 __device__ __forceinline__ void trav_descend(Trav& T, const NodeSrc& N, SQ_LDS StackT* stk, int stride) {
     v4f q0, q1; int ax; uint32_t left, right;
-    const uint32_t parent = T.cur;
+    // Culling (sq_cull_boxes): a child whose culling box the ray misses returns Nothing without being visited -- for a leaf,
+    // mollerTrumbore would reject every triangle (src/BIH.hs:105-109); for a branch, every leaf below it.  The boxes of
+    // both children are requested first, so that their latency overlaps the branch's own reads and slab tests.
+    typename NodeSrc::CullBoxes cb;
+    bool use_cull = false;
+    if constexpr (NodeSrc::kCull) { use_cull = T.cull && N.cull_on; if (use_cull) cb = N.cull_load(T.cur); }
     if constexpr (NodeSrc::kBoxInRegisters) {
         const BranchTail B = N.tail(T.cur);
         q0 = v4f{ T.blo.x, T.blo.y, T.blo.z, B.lmax }; q1 = v4f{ T.bhi.x, T.bhi.y, T.bhi.z, B.rmin };
@@ -567,6 +582,12 @@ __device__ __forceinline__ void trav_descend(Trav& T, const NodeSrc& N, SQ_LDS S
         iL = slab(q0.x, q0.y, q0.z, lhx, lhy, lhz, T.o, T.df);
         iR = slab(rlx, rly, rlz, q1.x, q1.y, q1.z, T.o, T.df);
     }
+    if constexpr (NodeSrc::kCull) {
+        // With a child known to return Nothing the Branch equation reduces to the other child's value, whatever isClose says
+        // (src/BIH.hs:113-119: near = Nothing -> far; far = Nothing -> near in all three alternatives), i.e. to the
+        // single-child equations, and no frame is pushed: "intersects" below means "intersects and may hold a hit".
+        if (use_cull) { iL = iL && N.cull_test(cb, true, T.df, T.nodf); iR = iR && N.cull_test(cb, false, T.df, T.nodf); }
+    }
     bool went_left;
     if (iL && iR) {
         const bool l2r = sq::axis_of(T.d, ax) > 0;                      // src/BIH.hs:127
@@ -578,11 +599,6 @@ __device__ __forceinline__ void trav_descend(Trav& T, const NodeSrc& N, SQ_LDS S
     T.cur = went_left ? left : right;
     if constexpr (NodeSrc::kBoxInRegisters) {                           // the chosen child's box (src/BIH.hs:130-141)
         if (went_left) T.bhi = sq::mk(lhx, lhy, lhz); else T.blo = sq::mk(rlx, rly, rlz);
-    }
-    if constexpr (NodeSrc::kCull) {
-        // a child whose culling box the ray misses returns Nothing without being visited (sq_cull_boxes): for a leaf,
-        // mollerTrumbore would reject every triangle (src/BIH.hs:105-109)
-        if (T.cull && N.cull_on && !N.child_hit(parent, went_left, T.cur, T.df, T.nodf)) { T.R.tri = -1; T.mode = M_UNWIND; return; }
     }
     if (T.cur & kLeafBit) T.mode = M_LEAF;
 }
@@ -688,9 +704,7 @@ __device__ __forceinline__ void trav_unwind(Trav& T, const NodeSrc& N, const Tri
         if (l2r) { if (ax == 0) T.blo.x = B.rmin; else if (ax == 1) T.blo.y = B.rmin; else T.blo.z = B.rmin; }
         else     { if (ax == 0) T.bhi.x = B.lmax; else if (ax == 1) T.bhi.y = B.lmax; else T.bhi.z = B.lmax; }
     }
-    if constexpr (NodeSrc::kCull) {
-        if (T.cull && N.cull_on && !N.child_hit(e, !l2r, T.cur, T.df, T.nodf)) { T.R.tri = -1; T.mode = M_UNWIND; return; }   // as in trav_descend
-    }
+    // (no culling test here: a FAR frame is only pushed for a far child whose culling box the ray hits, trav_descend)
     T.mode = (T.cur & kLeafBit) ? M_LEAF : M_DESCEND;
 }
 
