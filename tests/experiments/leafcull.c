@@ -84,13 +84,13 @@ static int bfs_of(const node* nd) { size_t h = ((uintptr_t)nd >> 4) * 2654435761
 static const sqo_bounds* box_fast(const node* nd) { size_t h = ((uintptr_t)nd >> 4) * 2654435761u & (g_tabn - 1); while (g_tab[h].k != nd) h = (h + 1) & (g_tabn - 1); return &g_nb[g_tab[h].v].box; }
 
 typedef struct { uint64_t rays, leaf, tri, branch, leaf_culled, sub_culled, mism; } stats;
-static __thread stats S[4];
-static stats G[4]; static pthread_mutex_t gmu = PTHREAD_MUTEX_INITIALIZER;
+static __thread stats S[5];
+static stats G[5]; static pthread_mutex_t gmu = PTHREAD_MUTEX_INITIALIZER;
 
 /* variant 1: cull leaves by their tight box; variant 2: cull every child (leaf or branch) by its tight box */
 static sqo_hit rec(int variant, sqo_bounds bbox, const node* nd, V3 o, V3 d, stats* s) {
     sqo_hit none; memset(&none, 0, sizeof none); none.tri = -1;
-    if (variant >= 1 && (nd->kind == 3 || variant == 2 || (variant == 3 && bfs_of(nd) >= g_b0))) {
+    if (variant >= 1 && (nd->kind == 3 || variant == 2 || variant == 4 || (variant == 3 && bfs_of(nd) >= g_b0))) {
         if (!sqo_intersects_bb(box_fast(nd), o, d)) { if (nd->kind == 3) s->leaf_culled++; else s->sub_culled++; return none; }
     }
     if (nd->kind == 3) {
@@ -113,6 +113,13 @@ static sqo_hit rec(int variant, sqo_bounds bbox, const node* nd, V3 o, V3 d, sta
             float p = proj(ax, near.point);
             int isClose = l2r ? (p < rmin) : (p > lmax);
             if (isClose) return near;
+            if (variant == 4) {   /* entry parameter of the far child's culling box against the near hit's t (generous slack) */
+                const node* fc = l2r ? nd->r : nd->l; const sqo_bounds* fb = box_fast(fc);
+                float tn = 0; { float dx = near.point.x - o.x, dy = near.point.y - o.y, dz = near.point.z - o.z; float dd = d.x*d.x+d.y*d.y+d.z*d.z; tn = (dx*d.x+dy*d.y+dz*d.z)/dd; }
+                float t1 = (fb->lo.x - o.x)/d.x, t2 = (fb->hi.x - o.x)/d.x, t3 = (fb->lo.y - o.y)/d.y, t4 = (fb->hi.y - o.y)/d.y, t5 = (fb->lo.z - o.z)/d.z, t6 = (fb->hi.z - o.z)/d.z;
+                float tmin = fmaxf(fmaxf(fminf(t1,t2), fminf(t3,t4)), fminf(t5,t6));
+                if (tmin - 1e-3f > tn * 1.001f) { s->sub_culled++; return near; }
+            }
             sqo_hit far = l2r ? rec(variant, right, nd->r, o, d, s) : rec(variant, left, nd->l, o, d, s);
             return far.hit ? min_by_dist(near, far) : near;
         }
@@ -124,12 +131,12 @@ static sqo_hit rec(int variant, sqo_bounds bbox, const node* nd, V3 o, V3 d, sta
 }
 static void ray_hook(const void* bv, float ox, float oy, float oz, float dx, float dy, float dz, const void* outv) {
     const sqo_bih* b = bv; const sqo_hit* ref = outv; V3 o = v3(ox, oy, oz), d = v3(dx, dy, dz);
-    for (int v = 0; v < 4; v++) {
+    for (int v = 0; v < 5; v++) {
         S[v].rays++;
         sqo_hit h = rec(v, b->bounds, b->tree, o, d, &S[v]);
         if (h.hit != ref->hit || (h.hit && (h.tri != ref->tri || memcmp(&h.dist, &ref->dist, 4)))) S[v].mism++;
     }
-    if (S[0].rays % 4096 == 0) { pthread_mutex_lock(&gmu); for (int v = 0; v < 4; v++) { uint64_t* a = (uint64_t*)&G[v]; uint64_t* t = (uint64_t*)&S[v]; for (int k = 0; k < 7; k++) { a[k] += t[k]; t[k] = 0; } } pthread_mutex_unlock(&gmu); }
+    if (S[0].rays % 4096 == 0) { pthread_mutex_lock(&gmu); for (int v = 0; v < 5; v++) { uint64_t* a = (uint64_t*)&G[v]; uint64_t* t = (uint64_t*)&S[v]; for (int k = 0; k < 7; k++) { a[k] += t[k]; t[k] = 0; } } pthread_mutex_unlock(&gmu); }
 }
 int main(int argc, char** argv) {
     int spp = argc > 1 ? atoi(argv[1]) : 16, step = argc > 2 ? atoi(argv[2]) : 40; if (argc > 3) g_margin = (float)atof(argv[3]);
@@ -149,8 +156,8 @@ int main(int argc, char** argv) {
     sqo_camera cam; sqo_load_camera(camf, 0, &cam);
     sqo_counters c;
     sqo_render_rows_strided(b, &cam, spp, w, h, 0, step / 2, w, step, 8, 0, 0, 0, 0, &c);
-    const char* names[4] = { "reference", "leaf boxes", "leaf+subtree boxes", "leaf+deep subtrees" };
-    for (int v = 0; v < 4; v++) { stats* s = &G[v];
+    const char* names[5] = { "reference", "leaf boxes", "leaf+subtree boxes", "leaf+deep subtrees", "subtree + far skip" };
+    for (int v = 0; v < 5; v++) { stats* s = &G[v];
         printf("%-20s rays %llu  per ray: branch %.2f leaf %.2f tri %.2f  culled leaves %.2f subtrees %.2f  mismatches %llu\n", names[v],
                (unsigned long long)s->rays, (double)s->branch / s->rays, (double)s->leaf / s->rays, (double)s->tri / s->rays,
                (double)s->leaf_culled / s->rays, (double)s->sub_culled / s->rays, (unsigned long long)s->mism); }

@@ -23,5 +23,8 @@ for cull in (0, 1):
     rays, iters, unw, desc, wins, pairs, hits, refill, refl = st[:9]
     print(f"  per ray: lane-iterations {iters*64/rays:.2f}, returns {unw/rays:.2f}, branch steps {desc/rays:.2f}, triangle tests {pairs/rays:.2f}, hits folded {hits/rays:.3f}")
     print(f"  per iteration: lanes returning {unw/(iters*64):.3f}, lanes branching {desc/(iters*64):.3f}, windows {wins/iters:.3f}, window fill {pairs/max(wins*128,1):.3f}")
+    comb, rl, rw, sl, sw, hs = st[9:15]
+    print(f"  returns: COMBINE pops {comb/rays:.3f} per ray; t recomputed {rl/rays:.3f} per ray, in {rw/iters:.3f} of the iterations; "
+          f"distance compare {sl/rays:.3f} per ray, in {sw/iters:.3f} of the iterations; slow compares in the hit fold {hs/rays:.4f} per ray")
     ts = st[16:24]; tot = sum(ts)
     print("  wave cycles per iteration: " + ", ".join(f"{nm} {t/iters:.0f} ({100*t/tot:.0f}%)" for nm, t in zip(names, ts)) + f"; total {tot/iters:.0f}", flush=True)
