@@ -120,6 +120,8 @@ int  sq_get_stats(sq_device_scene* s, uint64_t* out, int32_t n, int32_t reset);
  *                        2 = two pipelines: even and odd sample batches run start to end on two streams, so that one
  *                            track's launches fill the other's ramp-downs (+1.9 % on the headline frame)
  *   "aux_blocks_per_cu"  workgroups per CU of the per-sample kernels (0 = default 8)
+ *   "descend_extra"      pooled trace kernel: further branch steps (default 2) a lane that keeps descending takes within one iteration,
+ *   "descend_lanes"      each taken only while at least this many lanes (default 16) of the wave want one
  *   "cull"               1 (default): a ray inside the limits of sq_cull_boxes (squigly_host.h) that misses a leaf's culling box
  *                        skips the leaf's triangle tests -- the reference's mollerTrumbore would reject them all, so no bit
  *                        changes; 0: every leaf the reference visits is tested */

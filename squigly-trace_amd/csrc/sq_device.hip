@@ -420,6 +420,7 @@ struct TraceArgs {
                                  //   launch does not end with a few waves still working through a full reservation
     int32_t refill_min;          // pooled form: idle lanes a wave collects before it fetches new rays for them
     int32_t flush_min;           // pooled form: a trailing part-filled window of the pair pool is run at once from this many pairs on
+    int32_t descend_extra, descend_lanes;   // pooled form: further branch steps per iteration for lanes that keep descending, and how many such lanes it takes
     int32_t pixel_major;         // queue ORDER: 0 = slot order (sample-major: neighbouring pixels, one sample each), 1 = all samples
                                  //   of a pixel in a row, so that a wave's rays start from one surface point (slots stay where they are)
     unsigned long long* stats;   // [0] rays traced; PROFILE builds: [1] advance iterations (waves), [2] lanes unwinding,
@@ -629,6 +630,14 @@ __global__ void __launch_bounds__(BLOCK) sq_trace_rays(const SceneView S, const 
             stamp(1);
             if (PROFILE) pl_desc += (T.mode == M_DESCEND);
             if (T.mode == M_DESCEND) trav_descend(T, N, stk, BLOCK);
+            // With the culling boxes a ray takes four branch steps per leaf it opens: lanes that are still descending take up
+            // to `descend_extra` more steps in this iteration (while at least `descend_lanes` of them are), instead of paying a
+            // whole iteration -- return step, leaf scan, windows -- per branch step.
+            for (int x = 0; x < A.descend_extra; ++x) {
+                if (__popcll(__ballot(T.mode == M_DESCEND)) < A.descend_lanes) break;
+                if (PROFILE) pl_desc += (T.mode == M_DESCEND);
+                if (T.mode == M_DESCEND) trav_descend(T, N, stk, BLOCK);
+            }
             stamp(2);
             if (T.mode == M_LEAF) {                                         // open the leaf (src/BIH.hs:105): Nothing so far
                 const int2 lf = G.leaf(T.cur);
@@ -889,7 +898,7 @@ struct sq_device_scene {
     // second stream of the overlapped schedule (launch_frame) and its event pool
     hipStream_t aux = nullptr; std::vector<hipEvent_t> events;
     int64_t opt_overlap = 0, opt_aux_blocks_per_cu = 0;
-    int64_t opt_pool = 1, opt_refill_min = 12, opt_flush_min = 40, opt_guided = 1, opt_primary_resident = 1, opt_pixel_major = -1, opt_cull = 1;
+    int64_t opt_pool = 1, opt_refill_min = 12, opt_flush_min = 40, opt_guided = 1, opt_primary_resident = 1, opt_pixel_major = -1, opt_cull = 1, opt_descend_extra = 2, opt_descend_lanes = 16;
 };
 
 namespace {
@@ -1404,7 +1413,7 @@ int launch_frame(sq_device_scene* s, const Frame& F, hipStream_t stream) {
         if (!s->opt_guided) guide_shift = 62;
         TraceArgs A{ W.org, W.dir, W.hit, W.state, level == 0 ? (int32_t)kRay1 : (int32_t)kRay2, (long long)s->work.slot_capacity, with_mirror_rays ? 1 : 0,
                      W.n_active, kc, W.head[level], n_lds, stack_cap, (int32_t)s->opt_straggler, chunk, guide_shift,
-                     (int32_t)s->opt_refill_min, (int32_t)s->opt_flush_min, (int32_t)pixel_major, W.stats };
+                     (int32_t)s->opt_refill_min, (int32_t)s->opt_flush_min, (int32_t)s->opt_descend_extra, (int32_t)s->opt_descend_lanes, (int32_t)pixel_major, W.stats };
         return timed([&] {
             void* kargs[] = { (void*)&S, (void*)&A };
             (void)hipLaunchKernel(trace_fn, dim3(trace_blocks), dim3(trace_threads), kargs, tr_lds, on);
@@ -1605,6 +1614,8 @@ extern "C" int sq_set_option(sq_device_scene* s, const char* key, int64_t value)
     if (!std::strcmp(key, "guided")) { s->opt_guided = value ? 1 : 0; return 0; }
     if (!std::strcmp(key, "primary_resident")) { s->opt_primary_resident = value ? 1 : 0; return 0; }
     if (!std::strcmp(key, "cull")) { s->opt_cull = value ? 1 : 0; return 0; }
+    if (!std::strcmp(key, "descend_extra")) { if (value < 0 || value > 16) return sq_set_error("descend_extra must be in 0..16"); s->opt_descend_extra = value; return 0; }
+    if (!std::strcmp(key, "descend_lanes")) { if (value < 1 || value > 64) return sq_set_error("descend_lanes must be in 1..64"); s->opt_descend_lanes = value; return 0; }
     if (!std::strcmp(key, "pixel_major")) { s->opt_pixel_major = value < 0 ? -1 : value != 0; return 0; }
     if (!std::strcmp(key, "refill_min")) { if (value < 1 || value > 64) return sq_set_error("refill_min must be in 1..64"); s->opt_refill_min = value; return 0; }
     if (!std::strcmp(key, "flush_min")) { if (value < 0 || value > 64) return sq_set_error("flush_min must be in 0..64"); s->opt_flush_min = value; return 0; }
