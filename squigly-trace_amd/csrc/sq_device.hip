@@ -612,6 +612,7 @@ __global__ void __launch_bounds__(BLOCK) sq_trace_rays(const SceneView S, const 
         bool carry = false;                 // wave-uniform: the previous iteration left queued pairs untested
         unsigned int pl_hit = 0, pl_hslow = 0;
         TravProf prof{};
+        BranchPf pf; pf.idx = 0xffffffffu; pf.cb_ok = false;   // near-child prefetch (SQ_DESCEND_PREFETCH; unused and optimised away when off)
         // PROFILE: wave time per section of the loop (s_memtime ticks = shader cycles; the stamps themselves cost ~10 %)
         unsigned long long tsec[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, tlast = PROFILE ? __builtin_amdgcn_s_memtime() : 0;
         auto stamp = [&](int sec) { if (PROFILE) { const unsigned long long now = __builtin_amdgcn_s_memtime(); tsec[sec] += now - tlast; tlast = now; } };
@@ -629,14 +630,14 @@ __global__ void __launch_bounds__(BLOCK) sq_trace_rays(const SceneView S, const 
             if (T.mode == M_UNWIND) trav_unwind(T, N, G, stk, BLOCK, PROFILE ? &prof : nullptr);
             stamp(1);
             if (PROFILE) pl_desc += (T.mode == M_DESCEND);
-            if (T.mode == M_DESCEND) trav_descend(T, N, stk, BLOCK);
+            if (T.mode == M_DESCEND) trav_descend(T, N, stk, BLOCK, &pf);
             // With the culling boxes a ray takes four branch steps per leaf it opens: lanes that are still descending take up
             // to `descend_extra` more steps in this iteration (while at least `descend_lanes` of them are), instead of paying a
             // whole iteration -- return step, leaf scan, windows -- per branch step.
             for (int x = 0; x < A.descend_extra; ++x) {
                 if (__popcll(__ballot(T.mode == M_DESCEND)) < A.descend_lanes) break;
                 if (PROFILE) pl_desc += (T.mode == M_DESCEND);
-                if (T.mode == M_DESCEND) trav_descend(T, N, stk, BLOCK);
+                if (T.mode == M_DESCEND) trav_descend(T, N, stk, BLOCK, &pf);
             }
             stamp(2);
             if (T.mode == M_LEAF) {                                         // open the leaf (src/BIH.hs:105): Nothing so far

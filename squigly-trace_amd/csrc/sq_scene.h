@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "sq_math.h"
 
@@ -552,16 +553,40 @@ __device__ __forceinline__ void trav_begin(Trav& T, const SceneView& S, uint32_t
         T.mode = M_DONE;                                                // src/BIH.hs:112 at the root
 }
 
+// Near-child prefetch (resident form, pooled kernel; -DSQ_DESCEND_PREFETCH=bits, 0 = off): the kernel is bound by the
+// latency of its dependent steps, and a branch step's chain is "branch data -> slab tests -> choose the child -> the child's
+// data".  Which child is NEAR only depends on the ray's direction sign on the split axis, known as soon as the reference
+// words arrive: its data (bit 1: the two quads + reference words from LDS; bit 2: its children's culling boxes from global
+// memory) is requested before the slab tests and used by the next branch step if the ray does descend into it.  The data
+// is a pure function of the branch index, so a prefetched record is valid for any ray that reaches that branch.
+#ifndef SQ_DESCEND_PREFETCH
+#define SQ_DESCEND_PREFETCH 0
+#endif
+struct BranchPf { uint32_t idx; BranchData B; ResidentNodes::CullBoxes cb; bool cb_ok; };
+
 // One Branch equation (src/BIH.hs:111-141).  Pre: mode == M_DESCEND.
 template <typename NodeSrc, typename StackT>
-__device__ __forceinline__ void trav_descend(Trav& T, const NodeSrc& N, SQ_LDS StackT* stk, int stride) {
+__device__ __forceinline__ void trav_descend(Trav& T, const NodeSrc& N, SQ_LDS StackT* stk, int stride, BranchPf* pf = nullptr) {
     v4f q0, q1; int ax; uint32_t left, right;
+    constexpr bool kPf = (SQ_DESCEND_PREFETCH != 0) && std::is_same<NodeSrc, ResidentNodes>::value;
+    bool have = false;
+    if constexpr (kPf) have = pf != nullptr && pf->idx == T.cur;
     // Culling (sq_cull_boxes): a child whose culling box the ray misses returns Nothing without being visited -- for a leaf,
     // mollerTrumbore would reject every triangle (src/BIH.hs:105-109); for a branch, every leaf below it.  The boxes of
     // both children are requested first, so that their latency overlaps the branch's own reads and slab tests.
     typename NodeSrc::CullBoxes cb;
     bool use_cull = false;
-    if constexpr (NodeSrc::kCull) { use_cull = T.cull && N.cull_on; if (use_cull) cb = N.cull_load(T.cur); }
+    if constexpr (NodeSrc::kCull) {
+        use_cull = T.cull && N.cull_on;
+        if constexpr (kPf && (SQ_DESCEND_PREFETCH & 2)) {
+            if (use_cull) { if (have && pf->cb_ok) cb = pf->cb; else cb = N.cull_load(T.cur); }
+        } else if (use_cull) cb = N.cull_load(T.cur);
+    }
+    if constexpr (kPf && (SQ_DESCEND_PREFETCH & 1)) {
+        BranchData B;
+        if (have) B = pf->B; else B = N.load(T.cur);
+        q0 = B.q0; q1 = B.q1; ax = B.axis; left = B.left; right = B.right;
+    } else
     if constexpr (NodeSrc::kBoxInRegisters) {
         const BranchTail B = N.tail(T.cur);
         q0 = v4f{ T.blo.x, T.blo.y, T.blo.z, B.lmax }; q1 = v4f{ T.bhi.x, T.bhi.y, T.bhi.z, B.rmin };
@@ -569,6 +594,14 @@ __device__ __forceinline__ void trav_descend(Trav& T, const NodeSrc& N, SQ_LDS S
     } else {
         const BranchData B = N.load(T.cur);
         q0 = B.q0; q1 = B.q1; ax = B.axis; left = B.left; right = B.right;
+    }
+    if constexpr (kPf) if (pf != nullptr) {                             // request the near child's data before the slab tests
+        const uint32_t near = (sq::axis_of(T.d, ax) > 0) ? left : right;   // src/BIH.hs:127
+        pf->idx = near;                                                 // a leaf reference never equals a branch's T.cur
+        if (!(near & kLeafBit)) {
+            if constexpr ((SQ_DESCEND_PREFETCH & 1) != 0) pf->B = N.load(near);
+            if constexpr ((SQ_DESCEND_PREFETCH & 2) != 0) { pf->cb_ok = use_cull; if (use_cull) pf->cb = N.cull_load(near); }
+        }
     }
     const float lmax = q0.w, rmin = q1.w;
     // left = bbox with hi[ax] := lmax ; right = bbox with lo[ax] := rmin   (src/BIH.hs:130-141)

@@ -10,7 +10,7 @@ bih = sqt.BIH(sqt.Mesh.from_obj(os.path.join(data, "scene.obj"), data)); cam = s
 ds = sqt.DeviceScene(bih, 0)
 w, h, n = 1920, 1080, 256
 ref = None
-for overlap, aux, slots_m in ((0, 0, 512), (1, 4, 512), (1, 2, 512), (1, 3, 512), (1, 6, 512), (1, 8, 512), (1, 4, 256), (1, 4, 128)):
+for overlap, aux, slots_m in ((0, 0, 512), (1, 4, 512), (2, 0, 512), (2, 4, 512), (1, 2, 512), (1, 8, 512), (2, 2, 512), (0, 0, 512)):
     ds.set_option("overlap", overlap); ds.set_option("aux_blocks_per_cu", aux); ds.set_option("slots", slots_m << 20)
     a, r = ds.render_rows(cam, n, w, h, want_avg=False); torch.cuda.synchronize()
     if ref is None: ref = r.clone()
