@@ -22,6 +22,10 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
          # v_pk_mul_f32 / v_pk_add_f32 issue at ~9.5 cycles per wave on gfx950 against ~2.6 for the scalar forms
          # (tools/ubench/valu_rate.hip): keep the SLP vectoriser from packing the fp32 vector math.
          "-fno-slp-vectorize",
+         # performance only (scheduling; bits unchanged): the trace kernel is bound by the latency of its dependent steps
+         # at 4 waves per SIMD, and the ILP-first machine scheduler measured -0.5 ... -1.3 % on all three scenes against
+         # the default (same gpurun call, tools/ab_variant.sh); max-memory-clause +-0, iterative-minreg +2 %
+         "-mllvm", "-amdgpu-sched-strategy=max-ilp",
          "-Wall", "-Wno-unused-function"]
 
 

@@ -45,7 +45,10 @@ using namespace sqd;
 
 constexpr int kBlock = 256;        // per-pixel / per-sample kernels
 constexpr int kTraceBlock = 512;   // persistent trace kernel, streaming form: 8 waves share one LDS copy of the top of the tree
-constexpr int kResidentBlock = 1024; // persistent trace kernel, resident form: one workgroup per CU owns the whole scene in LDS
+#ifndef SQ_RESIDENT_BLOCK
+#define SQ_RESIDENT_BLOCK 1024       // diagnostic builds: 768 / 512 = three / two waves per SIMD (how the frame time follows occupancy)
+#endif
+constexpr int kResidentBlock = SQ_RESIDENT_BLOCK; // persistent trace kernel, resident form: one workgroup per CU owns the whole scene in LDS
 constexpr int kOneshotRowBlock = 8; // rows per block when a one-shot call shards a frame over devices
 // Slots a wave reserves from the queue per atomic (multiple of 256 for the resident form).  Every reservation stalls
 // the wave for the atomic's round trip and then for the flag loads of the scan, and a sparse chunk (8 % of the slots
@@ -458,6 +461,16 @@ __device__ __forceinline__ void stage_resident_scene(const SceneView& S, int n_b
     SQ_LDS v2i* lrefs = to_lds<v2i>(lds + L.refs);
     SQ_LDS v4f* lv = to_lds<v4f>(lds + L.verts);
     SQ_LDS v4us* lt = to_lds<v4us>(lds + L.trix);
+    SQ_LDS v2f* lboxes = to_lds<v2f>(lds + L.quads + 16u * (uint32_t)n_branches);   // kBoxInRegisters: 24-byte boxes behind the 16-byte tails
+    if constexpr (ResidentNodes::kBoxInRegisters) {
+        for (int i = threadIdx.x; i < n_branches; i += BLOCK) {
+            const uint32_t* r = S.rbranch + 10 * (size_t)i;
+            lquads[i] = v4f{ __uint_as_float(r[3]), __uint_as_float(r[7]), __uint_as_float(r[8]), __uint_as_float(r[9]) };
+            lboxes[3 * i] = v2f{ __uint_as_float(r[0]), __uint_as_float(r[1]) };
+            lboxes[3 * i + 1] = v2f{ __uint_as_float(r[2]), __uint_as_float(r[4]) };
+            lboxes[3 * i + 2] = v2f{ __uint_as_float(r[5]), __uint_as_float(r[6]) };
+        }
+    } else
     for (int i = threadIdx.x; i < n_branches; i += BLOCK) {
         const uint32_t* r = S.rbranch + 10 * (size_t)i;
         lquads[i] = v4f{ __uint_as_float(r[0]), __uint_as_float(r[1]), __uint_as_float(r[2]), __uint_as_float(r[3]) };
@@ -470,7 +483,7 @@ __device__ __forceinline__ void stage_resident_scene(const SceneView& S, int n_b
         lt[i] = v4us{ (unsigned short)(t.x * 16u), (unsigned short)(t.y * 16u), (unsigned short)(t.z * 16u), t.w };
     }
     if (threadIdx.x < ResidentTris::kRunPad) lt[S.n_tris + threadIdx.x] = v4us{ 0, 0, 0, 0 };
-    N = ResidentNodes{ lquads, lquads + n_branches, lrefs, S.cull_child16 != nullptr, S.cull_child16, S.rtail };
+    N = ResidentNodes{ lquads, lquads + n_branches, lrefs, lboxes, S.cull_child16 != nullptr, S.cull_child16, S.rtail };
     G = ResidentTris{ lt };
     if ((uintptr_t)lv != 0) __builtin_trap();                              // the kernels that use this have no static LDS: dynamic LDS starts at address 0
 }
@@ -626,6 +639,9 @@ __global__ void __launch_bounds__(BLOCK) sq_trace_rays(const SceneView S, const 
                 if (exhausted && m == ~0ull) break;
             }
             stamp(0);
+#ifdef SQ_SETPRIO      // timing experiment (results unchanged): instruction-arbitration priority of a wave in its return / branch steps
+            __builtin_amdgcn_s_setprio(SQ_SETPRIO & 3);
+#endif
             if (PROFILE) pl_unw += (T.mode == M_UNWIND);
             if (T.mode == M_UNWIND) trav_unwind(T, N, G, stk, BLOCK, PROFILE ? &prof : nullptr);
             stamp(1);
@@ -640,6 +656,9 @@ __global__ void __launch_bounds__(BLOCK) sq_trace_rays(const SceneView S, const 
                 if (T.mode == M_DESCEND) trav_descend(T, N, stk, BLOCK, &pf);
             }
             stamp(2);
+#ifdef SQ_SETPRIO      // ... and in its leaf scan and pair windows (bits 3..2)
+            __builtin_amdgcn_s_setprio((SQ_SETPRIO >> 2) & 3);
+#endif
             if (T.mode == M_LEAF) {                                         // open the leaf (src/BIH.hs:105): Nothing so far
                 const int2 lf = G.leaf(T.cur);
                 lf_first = lf.x; lf_cnt = lf.y; T.R.tri = -1;

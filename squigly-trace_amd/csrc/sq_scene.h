@@ -16,6 +16,7 @@ constexpr uint32_t kLeafBit = 0x80000000u;   // child reference: leaf index | kL
 // pointer is always a ds_read, never a flat load, and cannot be merged with a global pointer.
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef int v2i __attribute__((ext_vector_type(2)));
+typedef float v2f __attribute__((ext_vector_type(2)));
 typedef unsigned short v4us __attribute__((ext_vector_type(4)));
 #define SQ_LDS __attribute__((address_space(3)))
 template <typename T> __device__ __forceinline__ SQ_LDS T* to_lds(void* generic) { return (SQ_LDS T*)generic; }
@@ -364,11 +365,21 @@ struct HybridNodes {            // first n_lds branches (top of the tree) in LDS
 //   reference word: bit 31 = leaf; leaf: bits 28..24 = triangle count (<= 31), bits 23..0 = first triangle;
 //                   branch: bits 23..0 = branch index.  Bits 30..29 of the LEFT word hold the split axis.
 constexpr uint32_t kResAxisMask = kAxisMask;
+#ifndef SQ_RES_BOX_IN_REGISTERS
+#define SQ_RES_BOX_IN_REGISTERS 0
+#endif
 struct ResidentNodes {
-    static constexpr bool kBoxInRegisters = false;   // LDS reads are cheap here and VALU is what binds: boxes are read, not tracked
+    // Round 1 read a branch's own box with every visit ("LDS reads are cheap and VALU is what binds").  After the pooled
+    // windows and the culling boxes it is the number of memory instructions that the frame time follows, so the box can
+    // ride in six registers instead (a child's box is its parent's with one plane replaced, src/BIH.hs:130-141): a branch
+    // step then reads ONE 16-byte tail record (lmax, rmin, left word, right word) instead of two quads and a reference
+    // pair; only a return re-reads the branch's own box (24 bytes, behind the tails).  Same 40 bytes per branch.
+    static constexpr bool kBoxInRegisters = SQ_RES_BOX_IN_REGISTERS != 0;
     // (lo, lmax) of all branches, then (hi, rmin) of all branches: a wave's read of either spreads over all 16 bank slots
+    // kBoxInRegisters: `quads` holds the tail records and `boxes` the 24-byte (lo.xyz, hi.xyz) records; quads_hi / refs unused
     const SQ_LDS v4f* quads; const SQ_LDS v4f* quads_hi;
     const SQ_LDS v2i* refs;       // 1 per branch
+    const SQ_LDS v2f* boxes;
     // Culling boxes (sq_cull_boxes) of a branch's two children -- leaves and whole subtrees -- as binary16 pairs, two quads
     // per branch in GLOBAL memory (20 KB for scene.obj: L1-resident).  The LDS has no room for them, and more to the point
     // the kernel is held by the CU's LDS pipe while its vector-memory path idles: the same boxes in the vertices' unused w
@@ -385,6 +396,12 @@ struct ResidentNodes {
     __device__ __forceinline__ v4f q0(uint32_t b) const { return quads[b]; }
     __device__ __forceinline__ v4f q1(uint32_t b) const { return quads_hi[b]; }
     __device__ __forceinline__ BranchData load(uint32_t b) const {
+        if constexpr (kBoxInRegisters) {
+            const v4f t = quads[b];
+            const v2f p0 = boxes[3 * b], p1 = boxes[3 * b + 1], p2 = boxes[3 * b + 2];
+            const uint32_t l = __float_as_uint(t.z);
+            return BranchData{ v4f{ p0.x, p0.y, p1.x, t.x }, v4f{ p1.y, p2.x, p2.y, t.y }, (int)((l >> 29) & 3u), l & ~kResAxisMask, __float_as_uint(t.w) };
+        }
         const v2i r = refs[b];
         return BranchData{ q0(b), q1(b), (int)(((uint32_t)r.x >> 29) & 3u), (uint32_t)r.x & ~kResAxisMask, (uint32_t)r.y };
     }
@@ -396,6 +413,11 @@ struct ResidentNodes {
         if (SQ_RES_TAIL_GLOBAL) {   // one global load (10 KB table, L1) instead of three LDS reads: the LDS pipe is what binds
             const uint4 t = rtail[b];
             return BranchTail{ __uint_as_float(t.x), __uint_as_float(t.y), (int)((t.z >> 29) & 3u), t.z & ~kResAxisMask, t.w };
+        }
+        if constexpr (kBoxInRegisters) {
+            const v4f t = quads[b];
+            const uint32_t l = __float_as_uint(t.z);
+            return BranchTail{ t.x, t.y, (int)((l >> 29) & 3u), l & ~kResAxisMask, __float_as_uint(t.w) };
         }
         const v2i r = refs[b];
         return BranchTail{ q0(b).w, q1(b).w, (int)(((uint32_t)r.x >> 29) & 3u), (uint32_t)r.x & ~kResAxisMask, (uint32_t)r.y };
