@@ -639,6 +639,14 @@ __global__ void __launch_bounds__(BLOCK) sq_trace_rays(const SceneView S, const 
                 if (exhausted && m == ~0ull) break;
             }
             stamp(0);
+#ifdef SQ_EXTRA_VALU   // timing experiment (results unchanged): N more independent integer VALU instructions per iteration of a wave
+            { int x0 = lane, x1 = lane + 1, x2 = lane + 2, x3 = lane + 3;
+#pragma unroll
+              for (int e = 0; e < SQ_EXTRA_VALU / 4; ++e) {
+                  asm volatile("v_add_u32 %0, %0, %1" : "+v"(x0) : "v"(lane)); asm volatile("v_add_u32 %0, %0, %1" : "+v"(x1) : "v"(lane));
+                  asm volatile("v_add_u32 %0, %0, %1" : "+v"(x2) : "v"(lane)); asm volatile("v_add_u32 %0, %0, %1" : "+v"(x3) : "v"(lane)); }
+              asm volatile("" :: "v"(x0), "v"(x1), "v"(x2), "v"(x3)); }
+#endif
 #ifdef SQ_SETPRIO      // timing experiment (results unchanged): instruction-arbitration priority of a wave in its return / branch steps
             __builtin_amdgcn_s_setprio(SQ_SETPRIO & 3);
 #endif
