@@ -149,7 +149,7 @@ def main():
     ap.add_argument("--width", type=int, default=0)         # overrides of the configuration (first dimension = image ROWS)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--spp", type=int, default=0)
-    ap.add_argument("--cpu-rows", type=int, default=96, help="rows of the frame timed on the CPU oracle")
+    ap.add_argument("--cpu-rows", type=int, default=240, help="rows of the frame timed on the CPU oracle (240 rows = 66 M samples: about 10 s on 16 cores)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-other", action="store_true", help="skip the C3/C5 stand-in configurations (N = 1 only)")
     ap.add_argument("--no-oneshot", action="store_true", help="skip the one-shot call's wall time (profiling runs: keeps the launch count per step)")
@@ -283,6 +283,12 @@ def main():
                              "frac": round(achieved / VALU_PEAK_TLANEOPS, 4),
                              "valu_issue_frac": round(issue, 4), "valu_lane_utilisation": round(lane_util, 4),
                              "valu_wave_instructions_per_launch": int(insts / launches_per_step),
+                             # rocprofv3's VALUBusy expression (4 x SQ_ACTIVE_INST_VALU / SIMDs / cycles), for information: most of
+                             # this kernel's instructions (compares, min/max, selects, integer, DPP) hold the pipe for 4 cycles, not
+                             # the 2 of the fp32 FMA rate that `peak` is priced on; injected VALU instructions cost half their
+                             # share of the kernel's time, so the pipe is about half of what binds
+                             "valu_busy_rocprof_expr": round(4.0 * active / (N_SIMD * CLOCK_HZ * trace_s_per_step), 3),
+                             "valu_time_elasticity_measured": 0.5,
                              # the other co-limiting unit: the CU's LDS (scene, stacks and the ds_bpermute ray pulls all go
                              # through it).  array_busy = SQ_LDS_IDX_ACTIVE / (256 CUs x cycles of the trace launches).
                              "lds": {"array_busy_frac": round(pmc["SQ_LDS_IDX_ACTIVE"] / (N_SIMD / 4 * CLOCK_HZ * trace_s_per_step), 4),

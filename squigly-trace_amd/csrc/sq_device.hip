@@ -299,7 +299,7 @@ __global__ void __launch_bounds__(kBlock) sq_mirror1_store(const Work W, long lo
 __global__ void __launch_bounds__(kBlock) sq_shade1(const SceneView S, const Frame F, const Work W, int k_count) {
     const int A = *W.n_active;
     struct First { uint8_t st; uint2 r; };
-    struct Second { float4 org, dir; int2 hit; };
+    struct Second { float4 dir; int2 hit; };      // ray 1 starts at the pixel's primary hit point P.p0 (sq_gen_bounce1 stored that very value): org is not re-read
     for (int a = blockIdx.x * kBlock + threadIdx.x; a < A; a += gridDim.x * kBlock) {
         const Pixel0 P = load_pixel0(S, F, W, a);
         const Surface& s0 = P.s0;
@@ -309,7 +309,7 @@ __global__ void __launch_bounds__(kBlock) sq_shade1(const SceneView S, const Fra
         auto first = [&](int kl) { First f; const long long sid = (long long)kl * A + a; f.st = W.state[sid]; f.r = W.rng12[sid]; return f; };
         auto second = [&](int kl, uint8_t st) {
             Second q{};
-            if (st == kRay1) { const long long sid = (long long)kl * A + a; q.org = W.org[sid]; q.dir = W.dir[sid]; q.hit = W.hit[sid]; }
+            if (st == kRay1) { const long long sid = (long long)kl * A + a; q.dir = W.dir[sid]; q.hit = W.hit[sid]; }
             return q;
         };
         int kl = blockIdx.y;
@@ -327,7 +327,7 @@ __global__ void __launch_bounds__(kBlock) sq_shade1(const SceneView S, const Fra
             f3 d1, p0;
             int2 hit;
             if (cur.st == kMirror) { d1 = d1_mirror; p0 = P.p0; hit = hit_mirror; }          // the pixel's mirror ray and its hit
-            else { d1 = sq::mk(q.dir.x, q.dir.y, q.dir.z); p0 = sq::mk(q.org.x, q.org.y, q.org.z); hit = q.hit; }
+            else { d1 = sq::mk(q.dir.x, q.dir.y, q.dir.z); p0 = P.p0; hit = q.hit; }
             const int tri1 = hit.y;
             if (tri1 < 0) {                                             // raytrace ... 1 = black
                 store_rad(W, sid, s0.surf * sq::mk(0, 0, 0) + s0.emit);
