@@ -566,6 +566,18 @@ def test_bench_launches_its_own_ranks(sqt):
     lines = [ln for ln in two.stdout.strip().splitlines() if ln.startswith("{")]
     assert len(lines) == 1, two.stdout                                  # exactly one line, rank 0's
     j2 = json.loads(lines[0])
+    # the driver's contract for the line: every key it reads, and the two objects this tier adds at N = 1
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert key in j1 and key in j2, key
+    assert j1["unit"] == "Msamples/s" and j1["higher_is_better"] is True and j1["vs_baseline"] is None and j1["dtype"] == "f32"
+    assert "workload" in j1["config"] and "model" not in j1["config"] and j1["steps"] == 1 and j1["warmup"] == 1
+    assert abs(j1["value"] - j1["config"]["samples_per_step"] / j1["ms_per_step"] / 1e3) <= 0.02 * j1["value"] + 0.01
+    roof = j1["roofline"]
+    assert roof["bound"] == "valu" and roof["kernel"] == "sq_trace_rays" and roof["launches"] >= 1 and roof["kernel_ms"] > 0
+    for key in ("achieved", "peak", "unit", "frac", "traffic"):
+        assert key in roof, key
+    assert roof["frac"] is None or 0 < roof["frac"] <= 1                # None: no PMC pass of this (overridden) workload is committed
+    assert "roofline" not in j2 and "cpu_baseline" not in j2            # N = 1 figures
     assert j1["n_gpus"] == 1 and j2["n_gpus"] == 2 and j2["scaling"] == "strong" and "not_a_measurement" in j2
     assert j2["config"]["samples_per_step"] == j1["config"]["samples_per_step"] == 96 * 64 * 8      # the SAME frame, shared
     assert j2["config"]["nonblack_pixels"] == j1["config"]["nonblack_pixels"] > 0                   # and the same image
