@@ -24,6 +24,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <chrono>
 #include <thread>
 #include <type_traits>
 #include <unordered_map>
@@ -1659,29 +1660,44 @@ struct OneshotPart {
     std::vector<float> avg; std::vector<uint8_t> rgb;
     int rc = 0; std::string error;
 };
+// direct_avg / direct_rgb: the caller's own image (only when this part is the whole frame, rows in order): the finished frame is
+// copied straight into it -- the only step left that can fail is that copy itself -- instead of through a staging vector.
 int oneshot_part(const sq_scene* scene, const sq_camera* cam, int32_t samples, int32_t w, int32_t h, int32_t cast,
-                 bool want_avg, bool want_rgb, OneshotPart& P) {
+                 bool want_avg, bool want_rgb, OneshotPart& P, float* direct_avg = nullptr, uint8_t* direct_rgb = nullptr) {
     const int32_t rows = sq_shard_rows(w, P.shard);
     if (rows <= 0) return 0;
+    // SQ_ONESHOT_TIMING=1: host wall time of each stage of the call on stderr (what a host that binds the one-shot call pays
+    // around the frame itself)
+    const bool timing = std::getenv("SQ_ONESHOT_TIMING") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const auto t0 = now();
     sq_device_scene* s = nullptr;
     if (sq_scene_upload(scene, P.device, &s)) return 1;
+    const auto t1 = now();
+    auto t2 = t1, t3 = t1, t4 = t1;
     const size_t npx = (size_t)rows * (size_t)h * 3;
     float* d_avg = nullptr; uint8_t* d_rgb = nullptr; hipStream_t stream = nullptr;
     auto body = [&]() -> int {
         SQ_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         if (want_avg) SQ_HIP(hipMalloc((void**)&d_avg, npx * sizeof(float)));
         if (want_rgb) SQ_HIP(hipMalloc((void**)&d_rgb, npx));
+        t2 = now();
         if (sq_render_rows_device(s, cam, samples, w, h, cast, P.shard, d_avg, d_rgb, stream)) return 1;
         SQ_HIP(hipStreamSynchronize(stream));
+        t3 = now();
         // staged through private buffers so nothing is written to the caller's memory on failure
-        if (want_avg) { P.avg.resize(npx); SQ_HIP(hipMemcpy(P.avg.data(), d_avg, npx * sizeof(float), hipMemcpyDeviceToHost)); }
-        if (want_rgb) { P.rgb.resize(npx); SQ_HIP(hipMemcpy(P.rgb.data(), d_rgb, npx, hipMemcpyDeviceToHost)); }
+        if (want_avg) { float* dst = direct_avg; if (!dst) { P.avg.resize(npx); dst = P.avg.data(); } SQ_HIP(hipMemcpy(dst, d_avg, npx * sizeof(float), hipMemcpyDeviceToHost)); }
+        if (want_rgb) { uint8_t* dst = direct_rgb; if (!dst) { P.rgb.resize(npx); dst = P.rgb.data(); } SQ_HIP(hipMemcpy(dst, d_rgb, npx, hipMemcpyDeviceToHost)); }
+        t4 = now();
         return 0;
     };
     const int rc = body();
     (void)hipFree(d_avg); (void)hipFree(d_rgb);
     if (stream) (void)hipStreamDestroy(stream);
     sq_scene_free(s);
+    if (timing) std::fprintf(stderr, "sq one-shot (device %d): upload %.2f ms, stream+buffers %.2f, render+sync %.2f, copy back %.2f, free %.2f\n",
+                             P.device, ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), ms(t4, now()));
     return rc;
 }
 
@@ -1730,8 +1746,12 @@ int render_oneshot(const sq_scene* scene, const sq_camera* cam, int32_t samples,
         P.rc = oneshot_part(scene, cam, samples, w, h, cast, out_avg != nullptr, out_rgb != nullptr, P);
         if (P.rc) P.error = sq_last_error();                      // the message is thread-local: carry it out
     };
-    if (G == 1) run(parts[0]);
-    else {
+    if (G == 1) {                                                  // one device renders every row in order: no staging, no de-interleave
+        if (oneshot_part(scene, cam, samples, w, h, cast, out_avg != nullptr, out_rgb != nullptr, parts[0], out_avg, out_rgb))
+            return sq_set_error("device %d (shard 0 of 1): %s", parts[0].device, std::string(sq_last_error()).c_str());
+        return 0;
+    }
+    {
         std::vector<std::thread> threads;
         for (int g = 1; g < G; ++g) threads.emplace_back(run, std::ref(parts[(size_t)g]));
         run(parts[0]);
