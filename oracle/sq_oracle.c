@@ -88,6 +88,7 @@ static int reduce_pio2(double x, double* r) {
     if (fabs(x) <= PIO4) { *r = x; return 0; }
     double fn = floor(x * INVPIO2 + 0.5);
     *r = (x - fn * PIO2_1) - fn * PIO2_1T;
+    if (!(fabs(fn) < 0x1p62)) return 0;     /* fn is a multiple of 4 from 2^54 on; the conversion below is undefined beyond long long (UBSan, host camera angles) */
     return (int)((long long)fn & 3);
 }
 double sqo_sin_d(double x) {

@@ -75,6 +75,10 @@ SQ_HD int reduce(double x, double& r) {
     if (__builtin_fabs(x) <= 0x1.921fb54442d18p-1) { r = x; return 0; }
     double fn = __builtin_floor(x * 0x1.45f306dc9c883p-1 + 0.5);
     r = (x - fn * 0x1.921fb54400000p+0) - fn * 0x1.0b4611a626331p-34;
+    // fn is integral; from 2^54 on it is a multiple of 4, and beyond the range of long long (or NaN) the conversion is
+    // undefined in C++ (found by a UBSan build of the host side on a camera file with an absurd angle): quadrant 0 there,
+    // which is both fn mod 4 and what the x86 conversion's 0x8000000000000000 gave
+    if (!(__builtin_fabs(fn) < 0x1p62)) return 0;
     return (int)((long long)fn & 3);
 }
 // sin and cos of the same argument share the reduction and both polynomials

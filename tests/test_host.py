@@ -113,10 +113,14 @@ def test_loader_edge_cases_match_oracle(sqt, O):
         sqt.Mesh.from_obj("/nonexistent.obj", DATA)
     with pytest.raises(sqt.SquiglyError):
         sqt.camera_from_text(b"0 7\n")
-    for ang in [(0.3, -1.2, 2.5), (0, 0, 0), (1.5707963267948966, 0, -0.09817477042468103), (100.0, -37.5, 6.25)]:
+    # the last three: angles whose quadrant count leaves the range of long long (the range reduction's integer conversion
+    # was undefined there; found by the ASan/UBSan build of the host side, tools/sanitize_host.sh) -- defined now, and the same bits on both sides (the two-term reduction is only accurate for moderate angles: that is the numeric spec)
+    for ang in [(0.3, -1.2, 2.5), (0, 0, 0), (1.5707963267948966, 0, -0.09817477042468103), (100.0, -37.5, 6.25),
+                (6.4631e21, 0.5, -1.0), (-3.0e30, 1.0e19, 7.3e18), (3.4e38, -3.4e38, 2.0 ** 63)]:
         r = (C.c_float * 9)()
         O.lib().sqo_rot_matrix_rads(*ang, O.TRIG_CRD, r)
-        assert np.array_equal(sqt.rot_matrix_rads(*ang).ravel(), np.array(list(r), np.float32))
+        got = sqt.rot_matrix_rads(*ang).ravel()
+        assert np.array_equal(got.view(np.uint32), np.array(list(r), np.float32).view(np.uint32))
 
 
 def test_render_without_gpu_fails_loudly_not_silently(sqt, product_scene):
