@@ -64,6 +64,9 @@ using LiveT = uint8_t;             // a live slot's index within its chunk
 #define SQ_POOL_KW 1
 #endif
 constexpr int kStatSlots = 32;            // sq_get_stats
+#ifndef SQ_STAGE_BATCHED
+#define SQ_STAGE_BATCHED 1
+#endif
 constexpr int kPoolWindows = SQ_POOL_KW;   // pooled trace kernel: pair windows a wave works on at a time
 #ifndef SQ_POOL_TPL
 #define SQ_POOL_TPL 2
@@ -478,11 +481,30 @@ __device__ __forceinline__ void stage_resident_scene(const SceneView& S, int n_b
         lquads[n_branches + i] = v4f{ __uint_as_float(r[4]), __uint_as_float(r[5]), __uint_as_float(r[6]), __uint_as_float(r[7]) };
         lrefs[i] = v2i{ (int)r[8], (int)r[9] };
     }
+#if SQ_STAGE_BATCHED
+    // Several loads in flight per thread before the first LDS store (the plain loops wait for every load before the next is issued):
+    // a trace launch's staging is on the path of every launch, and a rank's share of a frame at 8 ranks has three launches in 8.5 ms.
+    for (int base = threadIdx.x; base < S.n_verts; base += BLOCK * 4) {
+        float4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int i = base + k * BLOCK; if (i < S.n_verts) v[k] = S.verts4[i]; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int i = base + k * BLOCK; if (i < S.n_verts) lv[i] = v4f{ v[k].x, v[k].y, v[k].z, v[k].w }; }
+    }
+    for (int base = threadIdx.x; base < S.n_tris; base += BLOCK * 8) {     // vertex indices become byte offsets into the vertex table
+        ushort4 t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const int i = base + k * BLOCK; if (i < S.n_tris) t[k] = S.trix[i]; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const int i = base + k * BLOCK; if (i < S.n_tris) lt[i] = v4us{ (unsigned short)(t[k].x * 16u), (unsigned short)(t[k].y * 16u), (unsigned short)(t[k].z * 16u), t[k].w }; }
+    }
+#else
     for (int i = threadIdx.x; i < S.n_verts; i += BLOCK) { const float4 v = S.verts4[i]; lv[i] = v4f{ v.x, v.y, v.z, v.w }; }
     for (int i = threadIdx.x; i < S.n_tris; i += BLOCK) {                  // vertex indices become byte offsets into the vertex table
         const ushort4 t = S.trix[i];
         lt[i] = v4us{ (unsigned short)(t.x * 16u), (unsigned short)(t.y * 16u), (unsigned short)(t.z * 16u), t.w };
     }
+#endif
     if (threadIdx.x < ResidentTris::kRunPad) lt[S.n_tris + threadIdx.x] = v4us{ 0, 0, 0, 0 };
     N = ResidentNodes{ lquads, lquads + n_branches, lrefs, lboxes, S.cull_child16 != nullptr, S.cull_child16, S.rtail };
     G = ResidentTris{ lt };
