@@ -56,7 +56,10 @@ typedef struct {
  * x, y, samples, w).  Devices: all visible ones when the frame has >= 2^24 samples, else device 0; the
  * environment variable SQ_DEVICES="0,1,3" names them explicitly (an index may repeat).
  * out: w*h*3 bytes, row-major, w ROWS x h COLUMNS (massiv `w :. h`, src/Lib.hs:70-71,80), RGB8 =
- * rgbFloatToPixelRGB of each pixel (src/Lib.hs:93-104).  cast != 0 selects raycast (src/Lib.hs:141-151). */
+ * rgbFloatToPixelRGB of each pixel (src/Lib.hs:93-104).  cast != 0 selects raycast (src/Lib.hs:141-151).
+ * With one device the finished frame is copied straight into `out`; with several, each shard is staged and de-interleaved.  Either way
+ * nothing is written to `out` unless every device's render succeeded.  SQ_ONESHOT_TIMING=1 prints the call's stages (scene
+ * upload, buffers, render, copy back, free) on stderr. */
 int sq_render_rgb8(const sq_scene* scene, const sq_camera* cam, int32_t samples, int32_t w, int32_t h,
                    int32_t cast, uint8_t* out);
 /* out_avg: w*h*3 floats = the pre-tonemap `avg` of src/Lib.hs:88 (for tolerance checks). */
@@ -118,7 +121,8 @@ int  sq_get_stats(sq_device_scene* s, uint64_t* out, int32_t n, int32_t reset);
  *                        1 = two sample batches in flight: trace launches on the caller's stream, the per-sample
  *                            kernels beside them on an internal stream
  *                        2 = two pipelines: even and odd sample batches run start to end on two streams, so that one
- *                            track's launches fill the other's ramp-downs (+1.9 % on the headline frame)
+ *                            track's launches fill the other's ramp-downs (1 and 2: -3 % on the whole headline frame, nothing on
+ *                            half a frame or less, so both stay opt-in)
  *   "aux_blocks_per_cu"  workgroups per CU of the per-sample kernels (0 = default 8)
  *   "descend_extra"      pooled trace kernel: further branch steps (default 2) a lane that keeps descending takes within one iteration,
  *   "descend_lanes"      each taken only while at least this many lanes (default 16) of the wave want one
