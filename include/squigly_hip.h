@@ -112,6 +112,9 @@ int  sq_get_stats(sq_device_scene* s, uint64_t* out, int32_t n, int32_t reset);
  *                        1 = all samples of a pixel in a row (a wave's rays start at one surface point), -1 = choose (default:
  *                        1 when the triangles exceed the 4 MB L2s, else 0)
  *   "primary_resident"   1 = with a resident scene the primary rays are traced out of LDS too (default), 0 = from L2
+ *   "primary_pooled"     1 = the primary rays go through the pooled trace kernel (one slot per pixel, one launch) instead of the
+ *                        one-ray-per-lane pass: one rank's share of the headline frame at 8 ranks 8.20 -> 8.12 ms, the whole
+ *                        frame 54.2 -> 54.4 ms; default 0
  *   "guided"             1 = queue reservations shrink towards the end of a launch (default), 0 = fixed size
  *   "straggler_lanes"    pool = 0: lanes still traversing when a wave turns to its leaves (default 8)
  *   "trace_blocks_per_cu" streaming form: workgroups per CU (0 = as many as LDS allows, up to 4)

@@ -295,6 +295,33 @@ __global__ void __launch_bounds__(kBlock) sq_mirror1_store(const Work W, long lo
     }
 }
 
+// Primary rays through the pooled trace kernel (option "primary_pooled"): one slot per pixel of this shard, one trace launch with
+// k_count = 1, then the hits are compacted into the active-pixel list exactly as sq_primary does.  The one-ray-per-lane walk of
+// sq_primary(_resident) lasts as long as its most expensive wave (64 neighbouring pixels on dense geometry: 0.5 ms on the headline
+// scene however small the shard); the pooled leaf phase walks such a wave faster.  W.n_active[48] is the launch's queue length.
+__global__ void __launch_bounds__(kBlock) sq_primary_gen(const Frame F, const Work W, long long total) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) W.n_active[48] = (int32_t)total;
+    for (long long pix = (long long)blockIdx.x * kBlock + threadIdx.x; pix < total; pix += (long long)gridDim.x * kBlock) {
+        int y, x; pixel_coords(F, pix, y, x);
+        const f3 d = primary_dir(F.cam_rot, F.w, F.h, y, x);
+        W.state[pix] = kRay1;
+        W.org[pix] = make_float4(F.cam_pos[0], F.cam_pos[1], F.cam_pos[2], 0.0f);
+        W.dir[pix] = make_float4(d.x, d.y, d.z, 0.0f);
+    }
+}
+__global__ void __launch_bounds__(kBlock) sq_primary_store(const Work W, long long total) {
+    for (long long base = (long long)blockIdx.x * kBlock; base < total; base += (long long)gridDim.x * kBlock) {   // whole waves stay together (ballot)
+        const long long pix = base + threadIdx.x;
+        const bool in = pix < total;
+        const int2 hit = in ? W.hit[pix] : make_int2(0, -1);
+        const int a = wave_append(W.n_active, in && hit.y >= 0);
+        if (a >= 0) {
+            W.px_pixel[a] = (int32_t)pix; W.px_t0[a] = __int_as_float(hit.x); W.px_tri0[a] = hit.y;
+            W.px_sum[3 * a] = 0.0f; W.px_sum[3 * a + 1] = 0.0f; W.px_sum[3 * a + 2] = 0.0f;
+        }
+    }
+}
+
 // After ray 1: a miss finishes the sample; a hit either finishes it (absorbing surface) or puts ray 2 in the slot.
 // One thread per active pixel, like sq_gen_bounce1: the primary surface, the hit point and the pixel's mirror ray and its hit
 // are per-pixel values.  It waits on memory two thirds of its time, so a slot's state byte decides what else is read (nothing
@@ -950,7 +977,7 @@ struct sq_device_scene {
     // second stream of the overlapped schedule (launch_frame) and its event pool
     hipStream_t aux = nullptr; std::vector<hipEvent_t> events;
     int64_t opt_overlap = 0, opt_aux_blocks_per_cu = 0;
-    int64_t opt_pool = 1, opt_refill_min = 12, opt_flush_min = 40, opt_guided = 1, opt_primary_resident = 1, opt_pixel_major = -1, opt_cull = 1, opt_descend_extra = 2, opt_descend_lanes = 16;
+    int64_t opt_pool = 1, opt_refill_min = 12, opt_flush_min = 40, opt_guided = 1, opt_primary_resident = 1, opt_pixel_major = -1, opt_cull = 1, opt_descend_extra = 2, opt_descend_lanes = 16, opt_primary_pooled = 0;
 };
 
 namespace {
@@ -1443,7 +1470,9 @@ int launch_frame(sq_device_scene* s, const Frame& F, hipStream_t stream) {
     const size_t tr_lds = L.total;
     if (tr_lds > 64 * 1024) SQ_HIP(hipFuncSetAttribute(trace_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tr_lds));
     // primary rays: once per pixel.  With a resident scene they are traced out of LDS as well.
-    if (resident && s->opt_primary_resident) {
+    const bool primary_pooled = s->opt_primary_pooled && pool;          // ... or through the pooled trace kernel, below
+    if (primary_pooled) {
+    } else if (resident && s->opt_primary_resident) {
         const TraceLds Lp = trace_lds_layout(S.n_branches, true, S.n_verts, S.n_tris, kResidentBlock, stack_cap, (int)sizeof(StackT), false);
         SQ_HIP(hipFuncSetAttribute((const void*)sq_primary_resident<StackT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Lp.total));
         const long long need = (pixels + kResidentBlock - 1) / kResidentBlock;
@@ -1481,6 +1510,15 @@ int launch_frame(sq_device_scene* s, const Frame& F, hipStream_t stream) {
             (void)hipLaunchKernel(trace_fn, dim3(trace_blocks), dim3(trace_threads), kargs, tr_lds, on);
         }, "sq_trace_rays", on);
     };
+    if (primary_pooled) {
+        Work Wp = W; Wp.n_active = W.n_active + 48;                     // the launch's queue is the shard's pixels, not the active ones
+        SQ_HIP(hipMemsetAsync(W.head[0], 0, 32 * sizeof(int32_t), stream));
+        hipLaunchKernelGGL(sq_primary_gen, dim3(aux_blocks), dim3(kBlock), 0, stream, F, W, pixels);
+        SQ_HIP(hipGetLastError());
+        if (launch_trace(Wp, 1, 0, stream)) return 1;
+        hipLaunchKernelGGL(sq_primary_store, dim3(aux_blocks), dim3(kBlock), 0, stream, W, pixels);
+        SQ_HIP(hipGetLastError());
+    }
     // once per frame: the depth-0 mirror ray of every active pixel (reused by every sample that mirrors).  In the plain
     // schedule these rays ride at the head of the first batch's first bounce launch (slots behind the sample slots,
     // dequeued first); the overlapped schedules give them a launch of their own, before the tracks split.
@@ -1676,6 +1714,7 @@ extern "C" int sq_set_option(sq_device_scene* s, const char* key, int64_t value)
     if (!std::strcmp(key, "guided")) { s->opt_guided = value ? 1 : 0; return 0; }
     if (!std::strcmp(key, "primary_resident")) { s->opt_primary_resident = value ? 1 : 0; return 0; }
     if (!std::strcmp(key, "cull")) { s->opt_cull = value ? 1 : 0; return 0; }
+    if (!std::strcmp(key, "primary_pooled")) { s->opt_primary_pooled = value != 0; return 0; }
     if (!std::strcmp(key, "descend_extra")) { if (value < 0 || value > 16) return sq_set_error("descend_extra must be in 0..16"); s->opt_descend_extra = value; return 0; }
     if (!std::strcmp(key, "descend_lanes")) { if (value < 1 || value > 64) return sq_set_error("descend_lanes must be in 1..64"); s->opt_descend_lanes = value; return 0; }
     if (!std::strcmp(key, "pixel_major")) { s->opt_pixel_major = value < 0 ? -1 : value != 0; return 0; }

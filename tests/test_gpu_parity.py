@@ -149,11 +149,14 @@ def test_kernel_variants_agree(sqt, product_scene, oracle_scene, dev, w, h, n, s
     # variant 1 = per-pixel kernel; variant 2 = wavefront pipeline with the resident (LDS) or the streaming trace
     # kernel, with and without the lane-occupancy counters (a separate template instantiation)
     # ... and with the overlapped two-track schedule (several batches in flight on two streams)
-    for variant, resident, profile, overlap in ((1, 1, 0, 0), (2, 1, 0, 0), (2, 0, 0, 0), (2, 1, 1, 0), (2, 0, 1, 0), (2, 1, 0, 1), (2, 0, 0, 1)):
+    # ... and with the primary rays through the pooled trace kernel (option primary_pooled), both scene forms and the two-pipeline schedule
+    for variant, resident, profile, overlap, pooled_primary in ((1, 1, 0, 0, 0), (2, 1, 0, 0, 0), (2, 0, 0, 0, 0), (2, 1, 1, 0, 0), (2, 0, 1, 0, 0), (2, 1, 0, 1, 0), (2, 0, 0, 1, 0),
+                                                                (2, 1, 0, 0, 1), (2, 0, 0, 0, 1), (2, 1, 0, 2, 1)):
         dev.set_option("variant", variant)
         dev.set_option("resident", resident)
         dev.set_option("profile", profile)
         dev.set_option("overlap", overlap)
+        dev.set_option("primary_pooled", pooled_primary)
         dev.set_option("slots", slots)
         a, r = dev.render_rows(cam, n, w, h)
         torch.cuda.synchronize()
@@ -164,6 +167,7 @@ def test_kernel_variants_agree(sqt, product_scene, oracle_scene, dev, w, h, n, s
     dev.set_option("resident", 1)
     dev.set_option("profile", 0)
     dev.set_option("overlap", 0)
+    dev.set_option("primary_pooled", 0)
     dev.set_option("slots", 512 << 20)
     o, o8, _ = ob.render(ocam, n, w, h, threads=THREADS)
     for a, r in outs:
