@@ -239,8 +239,9 @@ def run_case(seed, kinds=12):
              "flush_min": int(rng.choice([0, 1, 40, 64])), "guided": int(rng.integers(0, 2)),
              "primary_resident": int(rng.integers(0, 2)), "pixel_major": int(rng.integers(0, 2)),
              "cull": int(rng.random() < 0.8), "descend_extra": int(rng.choice([0, 1, 2, 5])), "descend_lanes": int(rng.choice([1, 16, 40])),
-             # from the seed, not from rng: the draws that follow stay what they were for every recorded seed
-             "primary_pooled": int(((seed * 2654435761) >> 7) % 4 == 0)}
+             # from the seed, not from rng: the draws that follow stay what they were for every recorded seed.  Campaign seeds only
+             # (>= 2e6): the slice in `pytest -m gpu` (seeds 1000..1399, 504773) keeps the knobs it has always had
+             "primary_pooled": int(seed >= 2000000 and ((seed * 2654435761) >> 7) % 4 == 0)}
     for kv in os.environ.get("SQ_FUZZ_FORCE", "").split(","):          # e.g. SQ_FUZZ_FORCE=primary_pooled=1,cull=0
         if "=" in kv:
             knobs[kv.split("=")[0]] = int(kv.split("=")[1])
