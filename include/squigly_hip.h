@@ -127,6 +127,10 @@ int  sq_get_stats(sq_device_scene* s, uint64_t* out, int32_t n, int32_t reset);
  *                            track's launches fill the other's ramp-downs (1 and 2: -3 % on the whole headline frame, nothing on
  *                            half a frame or less, so both stay opt-in)
  *   "aux_blocks_per_cu"  workgroups per CU of the per-sample kernels (0 = default 8)
+ *   "coresidency"        diagnostic, default 0: the trace kernel keeps a gauge of its live workgroups and every wave of the per-sample
+ *                        kernels (RNG + bounce, shading) records whether it started / ended while (CUs - 8) or more of them were live,
+ *                        i.e. beside a resident trace workgroup on its own CU; sq_get_stats slots 24..27 = gauge, per-sample waves,
+ *                        started beside, ended beside (tools/gpu_overlap.py prints them per schedule)
  *   "descend_extra"      pooled trace kernel: further branch steps (default 2) a lane that keeps descending takes within one iteration,
  *   "descend_lanes"      each taken only while at least this many lanes (default 16) of the wave want one
  *   "cull"               1 (default): a ray inside the limits of sq_cull_boxes (squigly_host.h) that misses a leaf's culling box
@@ -151,6 +155,10 @@ int sq_debug_eval(int32_t device, int32_t op, const void* a, const void* b, int6
 
 int32_t     sq_device_count(void);
 int32_t     sq_abi_version(void);
+/* Identity of this build: the first 16 hex digits of a SHA-256 over the library's sources, the C headers and the compiler
+ * flags (squigly-trace_amd/build.py: source_id).  Profile files under profiles/ are stamped with it, and bench.py refuses to
+ * price a roofline with counters that were collected on a different build ("unknown" = built without build.py). */
+const char* sq_build_id(void);
 const char* sq_last_error(void);
 
 #ifdef __cplusplus

@@ -25,7 +25,9 @@ const sq_material* sq_mesh_materials(const sq_mesh* m);
 void sq_mesh_free(sq_mesh* m);
 /* What `--debug` prints while loading (src/Obj.hs:55-57): `print (head objs)` and `print mats`, in the text of Haskell's
  * derived Show instances (records, lists, `show :: Float -> String`).  The strings belong to the mesh; both are empty
- * for a mesh that did not come from .obj/.sq text, and *first_object is empty when the file has no object. */
+ * for a mesh that did not come from .obj/.sq text, and *first_object is empty when the file has no object (the reference's
+ * `head objs` throws there: the CLIs print "Prelude.head: empty list" and exit 1).  Names are escaped per GHC's showLitChar on
+ * the UTF-8 decoded text (control characters by name, \DEL, \SO\&H, code points > 127 in decimal with \& before a digit). */
 void sq_mesh_debug_show(const sq_mesh* m, const char** first_object, const char** materials);
 
 /* Obj.loadCamera (src/Obj.hs:60-70): "px py pz\nalpha beta gamma" -> position + rotMatrixRads. */

@@ -587,11 +587,15 @@ typedef struct {
 static void* worker(void* arg) {                                                      /* role of massiv Par, Lib.hs:73-74 */
     job_t* j = (job_t*)arg;
     ctx_t cx = { j->b, j->trig, j->rngv, &j->c };
+    /* work item = 32 columns of one row (a row of a 1M-triangle scene at 256 spp is seconds of work: whole rows would
+       leave most threads idle on the few-row samples the tests and bench.py time) */
+    const int cb = 32, per_row = (j->h + cb - 1) / cb;
     for (;;) {
-        pthread_mutex_lock(j->mu); int r = (*j->next_row)++; pthread_mutex_unlock(j->mu);
+        pthread_mutex_lock(j->mu); int item = (*j->next_row)++; pthread_mutex_unlock(j->mu);
+        int r = item / per_row, x0 = (item % per_row) * cb, x1 = x0 + cb < j->h ? x0 + cb : j->h;
         int y = j->y0 + r * j->ystep;
         if (y >= j->y1) break;
-        for (int x = 0; x < j->h; x++) {
+        for (int x = x0; x < x1; x++) {
             V3 a = render_pixel_avg(&cx, j->cam, j->n, j->cast, j->w, j->h, y, x);
             size_t off = ((size_t)r * (size_t)j->h + (size_t)x) * 3;
             if (j->avg) { j->avg[off] = a.x; j->avg[off + 1] = a.y; j->avg[off + 2] = a.z; }

@@ -3,7 +3,7 @@
 Import with importlib (the directory name contains a hyphen):
     sqt = importlib.import_module("squigly-trace_amd")
 """
-from ._native import Camera, Shard, SquiglyError, lib, LIB_PATH, EXPORTED_SYMBOLS, debug_eval  # noqa: F401
+from ._native import Camera, Shard, SquiglyError, lib, LIB_PATH, EXPORTED_SYMBOLS, debug_eval, build_id  # noqa: F401
 from .scene import BIH, Mesh, load_camera, camera_from_text, rot_matrix_rads       # noqa: F401
 from .render import Settings, render, render_rgb8, render_f32                       # noqa: F401
 from .png import write_png                                                          # noqa: F401

@@ -64,6 +64,7 @@ def lib():
     L.sq_last_error.restype = C.c_char_p
     L.sq_device_count.restype = i32
     L.sq_abi_version.restype = i32
+    L.sq_build_id.restype = C.c_char_p
     L.sq_render_rgb8.argtypes = [C.POINTER(Scene), C.POINTER(Camera), i32, i32, i32, i32, vp]
     L.sq_render_f32.argtypes = [C.POINTER(Scene), C.POINTER(Camera), i32, i32, i32, i32, vp]
     L.sq_scene_upload.argtypes = [C.POINTER(Scene), i32, C.POINTER(vp)]
@@ -140,6 +141,11 @@ def debug_eval(op, a, b=None, device=0):
     return out
 
 
+def build_id():
+    """sq_build_id(): hash of the sources and flags the loaded library was built from (build.py: source_id)."""
+    return lib().sq_build_id().decode()
+
+
 def check(rc):
     if rc != 0:
         raise SquiglyError(lib().sq_last_error().decode(errors="replace"))
@@ -149,7 +155,7 @@ EXPORTED_SYMBOLS = [
     # include/squigly_hip.h
     "sq_render_rgb8", "sq_render_f32", "sq_scene_upload", "sq_scene_free", "sq_shard_rows",
     "sq_shard_global_row", "sq_render_rows_device", "sq_kernel_timing", "sq_kernel_timing_reset",
-    "sq_set_option", "sq_get_stats", "sq_debug_eval", "sq_device_count", "sq_abi_version", "sq_last_error",
+    "sq_set_option", "sq_get_stats", "sq_debug_eval", "sq_device_count", "sq_abi_version", "sq_build_id", "sq_last_error",
     # include/squigly_host.h
     "sq_mesh_from_obj", "sq_mesh_from_text", "sq_mesh_from_arrays", "sq_mesh_num_tris",
     "sq_mesh_num_materials", "sq_mesh_tris", "sq_mesh_materials", "sq_mesh_free", "sq_camera_from_file",

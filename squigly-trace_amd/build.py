@@ -29,6 +29,23 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
          "-Wall", "-Wno-unused-function"]
 
 
+def source_id(extra=()):
+    """First 16 hex digits of SHA-256 over every source and header of the library, the flags and the extra -D options:
+    what sq_build_id() returns, and what tools/collect_profiles.py stamps its counter files with."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(SOURCES + HEADERS):
+        h.update(f.encode() + b"\0")
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    h.update("\0".join(FLAGS + sorted(extra)).encode())
+    return h.hexdigest()[:16]
+
+
+def id_flag(extra=()):
+    return ['-DSQ_BUILD_ID="%s"' % source_id(extra)]
+
+
 def hipcc():
     for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
         if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
@@ -37,8 +54,13 @@ def hipcc():
 
 
 def stale():
+    """True unless the in-tree library was built from exactly the sources and flags that are here now: it must carry the
+    current source_id() (file times alone can lie after a checkout or a copy)."""
     if not os.path.exists(OUT):
         return True
+    with open(OUT, "rb") as f:
+        if source_id().encode() not in f.read():
+            return True
     t = os.path.getmtime(OUT)
     deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > t for d in deps)
@@ -50,11 +72,11 @@ CLI = os.path.join(HERE, "bin", "squigly-trace")
 def build(force=False, extra=(), out=None):
     """out: build an experimental variant (extra -D flags) beside the product library; SQ_LIB_PATH selects it at load time."""
     if out is not None:
-        subprocess.check_call([hipcc()] + FLAGS + list(extra) + ["-x", "hip"] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", out])
+        subprocess.check_call([hipcc()] + FLAGS + list(extra) + id_flag(extra) + ["-x", "hip"] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", out])
         return out
     if not force and not stale() and os.path.exists(CLI):
         return OUT
-    cmd = [hipcc()] + FLAGS + list(extra) + ["-x", "hip"] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", OUT]
+    cmd = [hipcc()] + FLAGS + list(extra) + id_flag(extra) + ["-x", "hip"] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", OUT]
     subprocess.check_call(cmd)
     # the reference's executable (app/Main.hs) over the C-ABI
     os.makedirs(os.path.dirname(CLI), exist_ok=True)

@@ -44,6 +44,9 @@ def main(argv=None):
     mesh = Mesh.from_obj(settings.objPath, "./data")            # loadTris, app/Main.hs:58-61 + src/Obj.hs:52
     if settings.debug:                                          # src/Obj.hs:55-57: print (head objs); print mats
         first, mats = mesh.debug_show()
+        if not first:                                           # `head objs` of a file without objects throws in the reference
+            print("squigly-trace: Prelude.head: empty list", file=sys.stderr)
+            return 1
         print(first)
         print(mats)
     # loadBIH, app/Main.hs:63-75.  Both builds give the same arrays; the GPU one wins from a few 10^4 triangles up.

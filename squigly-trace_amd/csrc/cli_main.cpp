@@ -99,6 +99,7 @@ int main(int argc, char** argv) {
     if (debug) {                                                                                 // src/Obj.hs:55-57: print (head objs); print mats
         const char *first = "", *mats = "";
         sq_mesh_debug_show(mesh, &first, &mats);
+        if (!*first) { std::fprintf(stderr, "squigly-trace: Prelude.head: empty list\n"); return 1; }   // `head objs` of a file without objects throws
         std::printf("%s\n%s\n", first, mats);
     }
     sq_bih* bih = nullptr;

@@ -87,6 +87,7 @@ struct Frame {
     int32_t samples, w, h, cast;
     int32_t row_block, shard, n_shards, local_rows;
     float* out_avg; uint8_t* out_rgb;
+    int32_t diag;             // option "coresidency": the per-sample kernels and the trace kernel count who runs beside whom (sq_get_stats 24..27)
 };
 __device__ __forceinline__ void pixel_coords(const Frame& F, int pix, int& y, int& x) {   // 32-bit: cheap div/mod
     const int j = pix / F.h;
@@ -182,6 +183,18 @@ struct Work {                 // device workspace of one frame (HBM)
 // kMirror: the sample mirrors at depth 0 and shares the pixel's mirror ray (traced once per pixel); kDone: its radiance is in `rad`.
 constexpr uint8_t kDone = 0, kRay1 = 1, kMirror = 2, kRay2 = 3;
 
+// Diagnostic (option "coresidency", off by default; results unchanged): does a wave of a per-sample kernel run BESIDE the
+// resident trace workgroups?  The trace kernel keeps a gauge of its live workgroups in stats[24]; it runs one workgroup per
+// CU, so a per-sample wave that starts (stats[26]) or ends (stats[27]) while at least `full` of them are live shares its CU
+// with one.  stats[25] counts the per-sample waves that looked.
+constexpr int kDiagGauge = 24, kDiagWaves = 25, kDiagStartBeside = 26, kDiagEndBeside = 27;
+__device__ __forceinline__ void diag_aux_wave(const Work& W, int diag, bool at_start) {
+    if (!diag || (threadIdx.x & 63) != 0) return;
+    const unsigned long long live = atomicAdd(&W.stats[kDiagGauge], 0ull);
+    if (at_start) atomicAdd(&W.stats[kDiagWaves], 1ull);
+    if (live >= (unsigned long long)diag) atomicAdd(&W.stats[at_start ? kDiagStartBeside : kDiagEndBeside], 1ull);
+}
+
 // Appends `want` lanes of this wave to a list with one atomic: wave ballot + prefix rank.
 __device__ __forceinline__ int wave_append(int32_t* counter, bool want) {
     const unsigned long long m = __ballot(want);
@@ -239,6 +252,7 @@ __device__ __forceinline__ void store_rad(const Work& W, long long sid, f3 L) {
 // computed once, not 256 times; consecutive threads still write consecutive slots (sid = k * A + a).
 __global__ void __launch_bounds__(kBlock) sq_gen_bounce1(const SceneView S, const Frame F, const Work W, int k_base, int k_count) {
     const int A = *W.n_active;
+    diag_aux_wave(W, F.diag, true);
     for (int a = blockIdx.x * kBlock + threadIdx.x; a < A; a += gridDim.x * kBlock) {
         const Pixel0 P = load_pixel0(S, F, W, a);
         const bool absorbing = absorbs(S, P.s0);
@@ -268,6 +282,7 @@ __global__ void __launch_bounds__(kBlock) sq_gen_bounce1(const SceneView S, cons
             W.dir[sid] = make_float4(d1.x, d1.y, d1.z, 0.0f);
         }
     }
+    diag_aux_wave(W, F.diag, false);
 }
 
 // The depth-0 mirror ray of every active pixel, once per frame (slot a = active pixel a).
@@ -329,6 +344,7 @@ __global__ void __launch_bounds__(kBlock) sq_primary_store(const Work W, long lo
 // are requested two samples ahead and the rest one sample ahead.
 __global__ void __launch_bounds__(kBlock) sq_shade1(const SceneView S, const Frame F, const Work W, int k_count) {
     const int A = *W.n_active;
+    diag_aux_wave(W, F.diag, true);
     struct First { uint8_t st; uint2 r; };
     struct Second { float4 dir; int2 hit; };      // ray 1 starts at the pixel's primary hit point P.p0 (sq_gen_bounce1 stored that very value): org is not re-read
     for (int a = blockIdx.x * kBlock + threadIdx.x; a < A; a += gridDim.x * kBlock) {
@@ -399,6 +415,7 @@ __global__ void __launch_bounds__(kBlock) sq_shade1(const SceneView S, const Fra
             W.dir[sid] = make_float4(d2.x, d2.y, d2.z, __int_as_float(tri1));
         }
     }
+    diag_aux_wave(W, F.diag, false);
 }
 
 // After ray 2: L2 = s2*0 + e2 (or black), L1 = s1*L2 + e1, L0 = s0*L1 + e0   (src/Lib.hs:135-137).
@@ -455,6 +472,7 @@ struct TraceArgs {
     int32_t refill_min;          // pooled form: idle lanes a wave collects before it fetches new rays for them
     int32_t flush_min;           // pooled form: a trailing part-filled window of the pair pool is run at once from this many pairs on
     int32_t descend_extra, descend_lanes;   // pooled form: further branch steps per iteration for lanes that keep descending, and how many such lanes it takes
+    int32_t diag;                // option "coresidency": keep the gauge of live workgroups in stats[24]
     int32_t pixel_major;         // queue ORDER: 0 = slot order (sample-major: neighbouring pixels, one sample each), 1 = all samples
                                  //   of a pixel in a row, so that a wave's rays start from one surface point (slots stay where they are)
     unsigned long long* stats;   // [0] rays traced; PROFILE builds: [1] advance iterations (waves), [2] lanes unwinding,
@@ -567,8 +585,11 @@ __global__ void __launch_bounds__(kResidentBlock) sq_primary_resident(const Scen
     }
 }
 
+#ifndef SQ_STREAM_MIN_WAVES
+#define SQ_STREAM_MIN_WAVES 1      // experiment: 6 = register budget for three 512-thread workgroups per CU in the streaming form
+#endif
 template <typename StackT, bool RESIDENT, int BLOCK, bool PROFILE, bool POOL>
-__global__ void __launch_bounds__(BLOCK) sq_trace_rays(const SceneView S, const TraceArgs A) {
+__global__ void __launch_bounds__(BLOCK, RESIDENT ? 1 : SQ_STREAM_MIN_WAVES) sq_trace_rays(const SceneView S, const TraceArgs A) {
     extern __shared__ float4 lds_raw[];
     char* lds = reinterpret_cast<char*>(lds_raw);
     const TraceLds L = trace_lds_layout(A.n_lds, RESIDENT, S.n_verts, S.n_tris, BLOCK, A.stack_cap, (int)sizeof(StackT), POOL);
@@ -585,11 +606,12 @@ __global__ void __launch_bounds__(BLOCK) sq_trace_rays(const SceneView S, const 
         root_ref = S.rroot;
     } else {
         for (int i = threadIdx.x; i < 3 * A.n_lds; i += BLOCK) { const float4 q = S.branches[i]; lquads[i] = v4f{ q.x, q.y, q.z, q.w }; }
-        N = HybridNodes{ lquads, S.branches, (uint32_t)A.n_lds, S.cull_child, S.cull_child != nullptr };
+        N = HybridNodes{ lquads, S.branches, (uint32_t)A.n_lds, S.cull_child, S.cull_child != nullptr, S.cull_child16 };
         G = GlobalTris{ S.tris, S.leaves, S.packed_leaves != 0, (size_t)S.n_tris * sizeof(DevTri) > ((size_t)4 << 20) };
         root_ref = S.root_ref;
     }
     __syncthreads();
+    if (A.diag && threadIdx.x == 0) atomicAdd(&A.stats[kDiagGauge], 1ull);
     const long long n_front = A.front ? (long long)(*A.n_active) : 0;
     const long long n = (long long)(*A.n_active) * A.k_count + n_front;          // queue positions; slot_of() maps them to slots
     const unsigned n_pix = (unsigned)(*A.n_active), kq = (unsigned)A.k_count;
@@ -876,6 +898,7 @@ __global__ void __launch_bounds__(BLOCK) sq_trace_rays(const SceneView S, const 
             stamp(7);
         }
         if (lane == 0) atomicAdd(&A.stats[0], n_traced);
+        if (A.diag && threadIdx.x == 0) atomicAdd(&A.stats[kDiagGauge], ~0ull);   // -1: the workgroup's first wave is leaving (the others follow within a ray's length)
         if (PROFILE) {
             if (lane == 0) { atomicAdd(&A.stats[1], pf_adv); atomicAdd(&A.stats[4], pf_leaf); atomicAdd(&A.stats[5], pf_outer); atomicAdd(&A.stats[7], pf_refill); }
             atomicAdd(&A.stats[2], (unsigned long long)pl_unw); atomicAdd(&A.stats[3], (unsigned long long)pl_desc);
@@ -914,6 +937,7 @@ __global__ void __launch_bounds__(BLOCK) sq_trace_rays(const SceneView S, const 
         if (T.mode == M_LEAF) trav_leaf(T, G);
     }
     if (lane == 0) atomicAdd(&A.stats[0], n_traced);
+    if (A.diag && threadIdx.x == 0) atomicAdd(&A.stats[kDiagGauge], ~0ull);
     if (PROFILE) {
         if (lane == 0) { atomicAdd(&A.stats[1], pf_adv); atomicAdd(&A.stats[4], pf_leaf); atomicAdd(&A.stats[6], pf_outer); atomicAdd(&A.stats[7], pf_refill); }
         atomicAdd(&A.stats[2], (unsigned long long)pl_unw); atomicAdd(&A.stats[3], (unsigned long long)pl_desc);
@@ -977,7 +1001,7 @@ struct sq_device_scene {
     // second stream of the overlapped schedule (launch_frame) and its event pool
     hipStream_t aux = nullptr; std::vector<hipEvent_t> events;
     int64_t opt_overlap = 0, opt_aux_blocks_per_cu = 0;
-    int64_t opt_pool = 1, opt_refill_min = 12, opt_flush_min = 40, opt_guided = 1, opt_primary_resident = 1, opt_pixel_major = -1, opt_cull = 1, opt_descend_extra = 2, opt_descend_lanes = 16, opt_primary_pooled = 0;
+    int64_t opt_pool = 1, opt_refill_min = 12, opt_flush_min = 40, opt_guided = 1, opt_primary_resident = 1, opt_pixel_major = -1, opt_cull = 1, opt_descend_extra = 2, opt_descend_lanes = 16, opt_primary_pooled = 0, opt_coresidency = 0;
 };
 
 namespace {
@@ -1181,7 +1205,7 @@ extern "C" int sq_scene_upload(const sq_scene* sc, int32_t device, sq_device_sce
     std::vector<uint32_t> rtail;                                      // resident form: a return's data per branch, one quad
     for (size_t b = 0; b * 10 < rbranch.size(); ++b) { const uint32_t* r = &rbranch[b * 10]; rtail.insert(rtail.end(), { r[3], r[7], r[8], r[9] }); }
     std::vector<uint32_t> cull16;                                     // the same boxes as binary16 pairs, for the resident form
-    if (!trix.empty() && !cull_child.empty()) {
+    if (!cull_child.empty()) {
         cull16.resize((size_t)nb * 8, 0u);
         for (int32_t b = 0; b < nb; ++b) for (int side = 0; side < 2; ++side) {
             const float* bx = &cull_child[(size_t)b * 16 + (size_t)side * 8];
@@ -1469,6 +1493,22 @@ int launch_frame(sq_device_scene* s, const Frame& F, hipStream_t stream) {
     }
     const size_t tr_lds = L.total;
     if (tr_lds > 64 * 1024) SQ_HIP(hipFuncSetAttribute(trace_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tr_lds));
+    static bool static_lds_checked = false;                           // per StackT instantiation; once per process is enough
+    if (resident && !static_lds_checked) {
+        // ResidentTris takes a vertex's byte offset for its LDS address: the vertex table must sit at LDS address 0, i.e. the
+        // kernels that stage a resident scene must own no static __shared__ (their dynamic LDS then starts at 0).  Checked here,
+        // where a violation is an error code, rather than by the device-side trap, where it would be a GPU abort.
+        const void* fns[5] = { (const void*)sq_trace_rays<StackT, true, kResidentBlock, false, true>, (const void*)sq_trace_rays<StackT, true, kResidentBlock, true, true>,
+                               (const void*)sq_trace_rays<StackT, true, kResidentBlock, false, false>, (const void*)sq_trace_rays<StackT, true, kResidentBlock, true, false>,
+                               (const void*)sq_primary_resident<StackT> };
+        for (const void* fn : fns) {
+            hipFuncAttributes attr{};
+            SQ_HIP(hipFuncGetAttributes(&attr, fn));
+            if (attr.sharedSizeBytes != 0)
+                return sq_set_error("internal error: a resident-scene kernel has %zu B of static LDS; its vertex table would not start at LDS address 0", (size_t)attr.sharedSizeBytes);
+        }
+        static_lds_checked = true;
+    }
     // primary rays: once per pixel.  With a resident scene they are traced out of LDS as well.
     const bool primary_pooled = s->opt_primary_pooled && pool;          // ... or through the pooled trace kernel, below
     if (primary_pooled) {
@@ -1504,7 +1544,8 @@ int launch_frame(sq_device_scene* s, const Frame& F, hipStream_t stream) {
         if (!s->opt_guided) guide_shift = 62;
         TraceArgs A{ W.org, W.dir, W.hit, W.state, level == 0 ? (int32_t)kRay1 : (int32_t)kRay2, (long long)s->work.slot_capacity, with_mirror_rays ? 1 : 0,
                      W.n_active, kc, W.head[level], n_lds, stack_cap, (int32_t)s->opt_straggler, chunk, guide_shift,
-                     (int32_t)s->opt_refill_min, (int32_t)s->opt_flush_min, (int32_t)s->opt_descend_extra, (int32_t)s->opt_descend_lanes, (int32_t)pixel_major, W.stats };
+                     (int32_t)s->opt_refill_min, (int32_t)s->opt_flush_min, (int32_t)s->opt_descend_extra, (int32_t)s->opt_descend_lanes,
+                     (int32_t)(s->opt_coresidency ? 1 : 0), (int32_t)pixel_major, W.stats };
         return timed([&] {
             void* kargs[] = { (void*)&S, (void*)&A };
             (void)hipLaunchKernel(trace_fn, dim3(trace_blocks), dim3(trace_threads), kargs, tr_lds, on);
@@ -1664,6 +1705,7 @@ extern "C" int sq_render_rows_device(sq_device_scene* s, const sq_camera* cam, i
     F.samples = samples; F.w = w; F.h = h; F.cast = cast ? 1 : 0;
     F.row_block = sh.row_block; F.shard = sh.shard; F.n_shards = sh.n_shards; F.local_rows = rows;
     F.out_avg = d_avg; F.out_rgb = d_rgb;
+    F.diag = s->opt_coresidency ? std::max(1, s->n_cu - 8) : 0;   // "beside" = while all but a handful of the CUs hold a live trace workgroup
     hipStream_t stream = (hipStream_t)hip_stream;
     return s->small_index ? launch_frame<uint16_t>(s, F, stream) : launch_frame<uint32_t>(s, F, stream);
 }
@@ -1715,6 +1757,7 @@ extern "C" int sq_set_option(sq_device_scene* s, const char* key, int64_t value)
     if (!std::strcmp(key, "primary_resident")) { s->opt_primary_resident = value ? 1 : 0; return 0; }
     if (!std::strcmp(key, "cull")) { s->opt_cull = value ? 1 : 0; return 0; }
     if (!std::strcmp(key, "primary_pooled")) { s->opt_primary_pooled = value != 0; return 0; }
+    if (!std::strcmp(key, "coresidency")) { s->opt_coresidency = value != 0; return 0; }
     if (!std::strcmp(key, "descend_extra")) { if (value < 0 || value > 16) return sq_set_error("descend_extra must be in 0..16"); s->opt_descend_extra = value; return 0; }
     if (!std::strcmp(key, "descend_lanes")) { if (value < 1 || value > 64) return sq_set_error("descend_lanes must be in 1..64"); s->opt_descend_lanes = value; return 0; }
     if (!std::strcmp(key, "pixel_major")) { s->opt_pixel_major = value < 0 ? -1 : value != 0; return 0; }
@@ -1883,4 +1926,8 @@ extern "C" int32_t sq_device_count(void) {
     return n;
 }
 extern "C" int32_t sq_abi_version(void) { return SQ_ABI_VERSION; }
+#ifndef SQ_BUILD_ID
+#define SQ_BUILD_ID "unknown"
+#endif
+extern "C" const char* sq_build_id(void) { return SQ_BUILD_ID; }
 extern "C" const char* sq_last_error(void) { return sq_error_buffer(); }

@@ -182,17 +182,37 @@ std::string show_float(float x) {
 std::string show_v3(const float v[3]) {                 // V3 {_x = .., _y = .., _z = ..}  (src/V3.hs:5)
     return "V3 {_x = " + show_float(v[0]) + ", _y = " + show_float(v[1]) + ", _z = " + show_float(v[2]) + "}";
 }
-std::string show_string(const std::string& t) {         // show :: String -> String
-    std::string o = "\"";
-    for (size_t i = 0; i < t.size(); ++i) {
+// show :: String -> String, i.e. showList over GHC.Show.showLitChar.  The reference reads its files with readFile, which
+// decodes them (UTF-8 in any modern locale) to code points before the parser sees them: a name is shown per CODE POINT.
+//   > '\DEL'  -> \ddd (decimal), followed by \& if a digit comes next      '\DEL' -> \DEL      '\\' -> \\     '"' -> \"
+//   >= ' '    -> itself              \a \b \f \n \r \t \v by letter            \SO -> \SO, followed by \& if an 'H' comes next
+//   other control characters by their ASCII names (\NUL \SOH ... \US)
+// A byte sequence that is not valid UTF-8 makes the reference's readFile throw; here each such byte is shown as the code
+// point of the same number (Latin-1), which no test can pin.
+std::string show_string(const std::string& t) {
+    static const char* const kAscii[32] = { "NUL", "SOH", "STX", "ETX", "EOT", "ENQ", "ACK", "a", "b", "t", "n", "v", "f", "r", "SO", "SI",
+                                            "DLE", "DC1", "DC2", "DC3", "DC4", "NAK", "SYN", "ETB", "CAN", "EM", "SUB", "ESC", "FS", "GS", "RS", "US" };
+    std::vector<uint32_t> cps;
+    for (size_t i = 0; i < t.size();) {                  // UTF-8 -> code points (shortest form, no surrogates, <= U+10FFFF)
         const unsigned char c = (unsigned char)t[i];
-        if (c == '"') o += "\\\"";
+        int n = c < 0x80 ? 1 : (c >> 5) == 6 ? 2 : (c >> 4) == 14 ? 3 : (c >> 3) == 30 ? 4 : 0;
+        uint32_t cp = n == 1 ? c : n == 2 ? (c & 0x1fu) : n == 3 ? (c & 0x0fu) : (c & 0x07u);
+        bool ok = n > 0 && i + (size_t)n <= t.size();
+        for (int k = 1; ok && k < n; ++k) { const unsigned char d = (unsigned char)t[i + (size_t)k]; ok = (d >> 6) == 2; cp = (cp << 6) | (d & 0x3fu); }
+        static const uint32_t kMin[5] = { 0, 0, 0x80, 0x800, 0x10000 };
+        if (ok && (cp < kMin[n] || cp > 0x10ffffu || (cp >= 0xd800u && cp <= 0xdfffu))) ok = false;
+        if (!ok) { cps.push_back(c); ++i; } else { cps.push_back(cp); i += (size_t)n; }
+    }
+    std::string o = "\"";
+    for (size_t i = 0; i < cps.size(); ++i) {
+        const uint32_t c = cps[i];
+        const uint32_t next = i + 1 < cps.size() ? cps[i + 1] : 0;
+        if (c > 127) { o += "\\" + std::to_string(c); if (next >= '0' && next <= '9') o += "\\&"; }
+        else if (c == 127) o += "\\DEL";
+        else if (c == '"') o += "\\\"";
         else if (c == '\\') o += "\\\\";
-        else if (c >= 32 && c < 127) o.push_back((char)c);
-        else {
-            o += "\\" + std::to_string((int)c);
-            if (i + 1 < t.size() && t[i + 1] >= '0' && t[i + 1] <= '9') o += "\\&";
-        }
+        else if (c >= 32) o.push_back((char)c);
+        else { o += std::string("\\") + kAscii[c]; if (c == 14 && next == 'H') o += "\\&"; }
     }
     return o + "\"";
 }
@@ -473,7 +493,14 @@ extern "C" void sq_bih_free(sq_bih* b) { delete b; }
 //   every coordinate finite and <= 2^20 in magnitude (no overflow anywhere in the test), P <= 29 for every triangle of
 //   the leaf, 0.25 <= |d|^2 <= 1.5624 (primary rays have |d| <= 1.2248, bounce rays |d| = 1 or the incoming length), |o|^2 <= o2max
 //   = (2 max|vertex|)^2, and o, d, 1/d, o/d finite.
-// tests/test_cull.py searches for violations with adversarial grazing rays against exact (binary64 / rational) geometry.
+// Branch nodes: the box of a branch is the union (componentwise min / max) of its children's boxes, so each of its planes IS
+//   a plane of some leaf box below it, slack included.  A ray that mollerTrumbore accepts for a triangle of leaf L hits L's
+//   rho-box exactly; the union contains that box with L's slack or more on every side (a union plane sits further out by
+//   some Delta >= 0, which adds Delta of slack against 4u Delta / |d_k| of additional plane-value error), so the computed
+//   intervals of the union box contain the exact ones of L's rho-box and the ray passes the union's slab test as well.  Hence
+//   "misses the box of a subtree" implies "misses the box of every leaf below", and the whole subtree returns Nothing.
+// tests/test_cull.py searches for violations with adversarial grazing rays against exact (binary64 / rational) geometry: the
+// leaf box and the box of every ancestor, in fp32 and in the binary16 encoding, plane values as single-rounding FMAs.
 namespace {
 inline float f_down(double x) { float f = (float)x; if ((double)f > x) f = std::nextafterf(f, -INFINITY); return f; }
 inline float f_up(double x) { float f = (float)x; if ((double)f < x) f = std::nextafterf(f, INFINITY); return f; }

@@ -347,9 +347,25 @@ struct HybridNodes {            // first n_lds branches (top of the tree) in LDS
     static constexpr bool kCull = true;
     const SQ_LDS v4f* l; const float4* g; uint32_t n_lds;
     const float4* cull; bool cull_on;
+    // SQ_STREAM_CULL16: the children's culling boxes as binary16 pairs (2 quads per branch, as in the resident form) instead of
+    // fp32 (4 quads): every lane of a divergent load is a tag lookup of its own in the L1, and a branch visit is 7 of them
+    // (3 branch quads + 4 box quads).  Coarser boxes cull less (planes move outwards by up to 2^-10 of their magnitude).
+#ifndef SQ_STREAM_CULL16
+#define SQ_STREAM_CULL16 0
+#endif
+    const uint4* cull16;
+#if SQ_STREAM_CULL16
+    struct CullBoxes { uint4 l, r; };
+    __device__ __forceinline__ CullBoxes cull_load(uint32_t parent) const { return CullBoxes{ cull16[2 * (size_t)parent], cull16[2 * (size_t)parent + 1] }; }
+    __device__ __forceinline__ bool cull_test(const CullBoxes& c, bool left, f3 df, f3 nodf) const {
+        const uint4 w = left ? c.l : c.r;
+        return cull_slab_half(w.x, w.y, w.z, df, nodf);
+    }
+#else
     using CullBoxes = CullBoxes32;
     __device__ __forceinline__ CullBoxes cull_load(uint32_t parent) const { return cull_load32(cull, parent); }
     __device__ __forceinline__ bool cull_test(const CullBoxes& c, bool left, f3 df, f3 nodf) const { return cull_test32(c, left, df, nodf); }
+#endif
     __device__ __forceinline__ BranchData load(uint32_t b) const {
         if (b < n_lds) return unpack_branch(l[3 * b], l[3 * b + 1], l[3 * b + 2]);
         const float4 a = g[3 * b], c = g[3 * b + 1], d = g[3 * b + 2];

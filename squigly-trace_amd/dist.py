@@ -75,17 +75,35 @@ def gather_frame(local, w, row_block=ROW_BLOCK, group=None):
     h, c = local.shape[1], local.shape[2]
     send, gathered = plan.buffers(h, c, local.dtype, local.device)
     if local.shape[0] == plan.mx and local.is_contiguous():
-        send = local                                   # the common case: no staging copy
+        # The common case: no staging copy, the collective reads the renderer's output tensor itself.  That is safe because
+        # the collective is enqueued on (or ordered after) the stream the render was enqueued on, and because `local` is a
+        # tensor render_rows allocated for THIS frame: nothing rewrites it before the collective has read it.  A caller that
+        # passes its own reused buffer (render_rows(out_rgb=...)) must not enqueue the next render into it on another stream
+        # before this call's result has been consumed.
+        send = local
     else:
         send[: local.shape[0]].copy_(local)
     dist.all_gather_into_tensor(gathered.view(-1), send.view(-1), group=group)
     return gathered.index_select(0, plan.src)
 
 
-def render_frame(device_scene, cam, samples, w, h, cast=False, row_block=ROW_BLOCK, want="rgb", group=None):
-    """Render this rank's rows on its GPU and gather the frame ([w, h, 3], on every rank)."""
+def render_frame(device_scene, cam, samples, w, h, cast=False, row_block=ROW_BLOCK, want="rgb", group=None, events=None):
+    """Render this rank's rows on its GPU and gather the frame ([w, h, 3], on every rank).
+
+    events: a list that receives (start, rendered, gathered) torch.cuda.Event triples, one per call, recorded on the
+    current stream (bench.py turns them into this rank's render time and gather time per frame)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
+    ev = None
+    if events is not None:
+        ev = tuple(torch.cuda.Event(enable_timing=True) for _ in range(3))
+        ev[0].record()
     avg, rgb = device_scene.render_rows(cam, samples, w, h, cast=cast, shard=(row_block, rank, world),
                                         want_avg=(want == "avg"), want_rgb=(want == "rgb"))
-    return gather_frame(avg if want == "avg" else rgb, w, row_block, group)
+    if ev is not None:
+        ev[1].record()
+    frame = gather_frame(avg if want == "avg" else rgb, w, row_block, group)
+    if ev is not None:
+        ev[2].record()
+        events.append(ev)
+    return frame

@@ -57,3 +57,55 @@ def test_streaming_kernel_parity_on_large_scenes(sqt, O, which):
     torch.cuda.synchronize()
     assert np.array_equal(a.cpu().numpy().view(np.uint32), oc.view(np.uint32))
     ds.close()
+
+
+# Full-size frames of BASELINE configs[2] and configs[4] (their procedural stand-ins).  The oracle needs ~10 s per
+# full-spp row of these scenes on 16 cores (it tests every triangle of every leaf the reference visits: 1100-1600
+# tests per bounce ray), so FOUR rows spread over the frame are compared bit for bit; everything else about the
+# frame is checked GPU against GPU: culling on = culling off, a second render = the first, and eight interleaved
+# row shards (what eight ranks render) reassemble to the one-GPU frame.
+FULL = {"blob6": (lambda: G.blob_scene(6), 512, (97, 803, 1211, 1790)),
+        "heightfield708": (lambda: G.heightfield_scene(708), 256, (160, 741, 1302, 1874))}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["blob6", "heightfield708"])
+def test_full_size_frame_of_the_large_scenes(sqt, O, which):
+    import torch
+    from importlib import import_module
+    d = import_module("squigly-trace_amd.dist")
+    make, spp, rows = FULL[which]
+    obj, sq, camt = make()
+    mesh = sqt.Mesh.from_text(obj, sq)
+    bih = sqt.BIH(mesh, device=0)                      # the device build, as the bench and the CLI use for >= 50 000 triangles
+    ob = O.BIH(O.tris_from_text(obj, sq))
+    assert np.array_equal(bih.tris["v0"], ob.flatten()["a"]) and bih.height == ob.height
+    cam, ocam = sqt.camera_from_text(camt), O.camera_from_text(camt)
+    w, h = 1920, 1080
+    ds = sqt.DeviceScene(bih, 0)
+    avg, rgb = ds.render_rows(cam, spp, w, h)
+    torch.cuda.synchronize()
+    threads = min(os.cpu_count() or 1, 16)
+    sel = torch.tensor(rows, device=avg.device)
+    g, g8 = avg[sel].cpu().numpy(), rgb[sel].cpu().numpy()
+    for i, y in enumerate(rows):                       # one oracle call per row: rows=(y, y + 1)
+        o, o8, _ = ob.render(ocam, spp, w, h, threads=threads, rows=(y, y + 1))
+        assert np.array_equal(g[i].view(np.uint32), o[0].view(np.uint32)), \
+            f"{which} row {y}: {int((g[i].view(np.uint32) != o[0].view(np.uint32)).any(-1).sum())} of {h} pixels differ"
+        assert np.array_equal(g8[i], o8[0])
+    assert int((rgb.sum(-1) > 0).sum()) > w * h // 4   # a real picture, not a black frame that happens to match
+    # culling boxes off: the reference's every visit is made; same bits
+    ds.set_option("cull", 0)
+    a0, r0 = ds.render_rows(cam, spp, w, h)
+    torch.cuda.synchronize()
+    assert torch.equal(a0.view(torch.int32), avg.view(torch.int32)) and torch.equal(r0, rgb)
+    ds.set_option("cull", 1)
+    # what eight ranks render: interleaved blocks of d.ROW_BLOCK rows, reassembled
+    frame = torch.zeros_like(avg)
+    for r in range(8):
+        a, _ = ds.render_rows(cam, spp, w, h, shard=(d.ROW_BLOCK, r, 8), want_rgb=False)
+        frame[torch.tensor(d.shard_rows(w, d.ROW_BLOCK, r, 8), device=a.device)] = a
+    torch.cuda.synchronize()
+    assert torch.equal(frame.view(torch.int32), avg.view(torch.int32))
+    ds.close()
+    sqt.release_cached_memory()

@@ -37,17 +37,68 @@ def mt_accepts(o, d, v0, v1, v2):
         return ~((a > -eps) & (a < eps)) & ~((u < 0) | (u > 1)) & ~((v < 0) | (u + v > 1)) & (t > eps), a
 
 
+def fma32(a, b, c):
+    """fl32(a * b + c) with ONE rounding, for float32 arrays -- exactly what v_fma_f32 / v_fma_mix_f32 return.
+    a * b is exact in binary64 (24 + 24 bits); the sum is taken with TwoSum, and the binary64 sum is turned into the
+    round-to-odd value of the exact result (if inexact, whichever neighbour has an odd last bit), which then rounds to
+    binary32 as the exact value would (53 >= 24 + 2: no double rounding).  x86 long double (64-bit significand, the first
+    version of this test) is NOT enough: its own rounding can land on a binary32 midpoint."""
+    p = a.astype(np.float64) * b.astype(np.float64)
+    c = np.broadcast_to(c.astype(np.float64), p.shape)
+    with np.errstate(all="ignore"):
+        s = p + c
+        bb = s - p
+        err = (p - (s - bb)) + (c - bb)                      # exact: s + err == p + c
+    fin = np.isfinite(s) & np.isfinite(err) & (err != 0)
+    bits = s.view(np.int64).copy() if s.flags.writeable else s.copy().view(np.int64)
+    even = (bits & 1) == 0
+    toward_larger_magnitude = (err > 0) == (s > 0)           # exact value lies on this side of s
+    adj = fin & even
+    # for s == 0 (cannot happen with err != 0: the sum of two finite doubles that rounds to 0 is exact) nothing to do
+    step = np.where(toward_larger_magnitude, 1, -1)
+    bits = np.where(adj, bits + step, bits)
+    return bits.view(np.float64).astype(np.float32)
+
+
 def slab_passes(box, o, d):
     """The kernels' culling slab test: plane value = fma(l, 1/d, -o * (1/d)) with one rounding, v_min/v_max, tmax > 0 && tmin < tmax."""
     with np.errstate(all="ignore"):
         df = f32(1) / d
         nodf = -o * df
-        ld = np.longdouble
-        tl = (box[:, 0:3].astype(ld) * df.astype(ld) + nodf.astype(ld)).astype(f32)
-        th = (box[:, 3:6].astype(ld) * df.astype(ld) + nodf.astype(ld)).astype(f32)
+        tl = fma32(box[:, 0:3], df, nodf)
+        th = fma32(box[:, 3:6], df, nodf)
     tmin = np.minimum(tl, th).max(1)
     tmax = np.maximum(tl, th).min(1)
     return (tmax > 0) & (tmin < tmax)
+
+
+def test_fma32_is_a_single_rounding():
+    """Against exact rational arithmetic, on random operands and on operands built so that a * b + c sits within a few
+    binary64 ulps of a binary32 rounding midpoint (where long double or plain binary64 evaluation double-rounds)."""
+    from fractions import Fraction
+    rng = np.random.default_rng(3)
+    n = 4000
+    a = (rng.standard_normal(n) * 10.0 ** rng.uniform(-3, 3, n)).astype(f32)
+    b = (rng.standard_normal(n) * 10.0 ** rng.uniform(-3, 3, n)).astype(f32)
+    c = (rng.standard_normal(n) * 10.0 ** rng.uniform(-3, 3, n)).astype(f32)
+    # midpoints: pick a float32 r and its successor, m = their mean; c := the float32 nearest to m - a*b
+    r = (rng.standard_normal(n) * 10.0 ** rng.uniform(-2, 2, n)).astype(f32)
+    mid = (r.astype(np.float64) + np.nextafter(r, f32(np.inf)).astype(np.float64)) / 2
+    a2 = (rng.standard_normal(n)).astype(f32); b2 = (rng.standard_normal(n) * 1e-4).astype(f32)
+    c2 = (mid - a2.astype(np.float64) * b2.astype(np.float64)).astype(f32)
+    A, B, Cc = np.concatenate([a, a2]), np.concatenate([b, b2]), np.concatenate([c, c2])
+    got = fma32(A, B, Cc)
+
+    def rn32(q):                                             # correctly rounded binary32 of a Fraction
+        if q == 0:
+            return f32(0)
+        lo = f32(float(q))                                   # float(q) is correctly rounded to binary64: within half a binary32 ulp of the answer
+        cands = sorted({float(lo), float(np.nextafter(lo, f32(-np.inf))), float(np.nextafter(lo, f32(np.inf)))})
+        best = min(cands, key=lambda v: (abs(Fraction(v) - q), int(np.array([v], f32).view(np.uint32)[0]) & 1))
+        return f32(best)
+    for i in range(len(A)):
+        want = rn32(Fraction(float(A[i])) * Fraction(float(B[i])) + Fraction(float(Cc[i])))
+        assert got[i] == want, (i, A[i], B[i], Cc[i], got[i], want)
 
 
 def half_box(box):
@@ -151,6 +202,14 @@ def test_accepted_triangles_pass_their_leafs_culling_box(scene):
     assert finite[is_leaf].mean() > 0.5                         # the lemma must not be vacuous
     total_acc = 0
     worst = 0.0
+    ancestors_checked = 0
+    parent = np.full(len(nodes), -1, np.int64)               # pre-order: left child = i + 1, right child = link
+    for i, nd in enumerate(nodes):
+        if nd["kind"] & 3 != 3:
+            parent[i + 1] = i; parent[nd["link"]] = i
+    inner = ~is_leaf
+    assert np.all(boxes[inner][:, :3] <= np.minimum(boxes[np.flatnonzero(inner) + 1][:, :3], boxes[nodes["link"][inner]][:, :3]))   # a branch's box contains its children's
+    assert np.all(boxes[inner][:, 3:] >= np.maximum(boxes[np.flatnonzero(inner) + 1][:, 3:], boxes[nodes["link"][inner]][:, 3:]))
     for rounds in range(3):
         ks, os_, ds = [], [], []
         for eps_scale in (0.05, 0.5, 2.0):
@@ -176,6 +235,18 @@ def test_accepted_triangles_pass_their_leafs_culling_box(scene):
         for bx, name in ((boxes, "fp32"), (hboxes, "binary16")):
             ok = slab_passes(bx[leaf], o, d)
             assert ok.all(), (name, int((~ok).sum()), o[~ok][:3], d[~ok][:3], k[~ok][:3])
+            # ... and the box of EVERY ancestor (the union of its subtree's boxes): trav_descend skips a whole subtree on a
+            # miss of its box, before any frame is pushed, so an accepted ray must pass all of them on the way down
+            cur = leaf.copy()
+            while True:
+                up = parent[cur]
+                live = up >= 0
+                if not live.any():
+                    break
+                cur = np.where(live, up, cur)
+                ok = slab_passes(bx[cur[live]], o[live], d[live])
+                assert ok.all(), (name, "ancestor", int((~ok).sum()))
+                ancestors_checked += int(live.sum())
         # How much of a triangle's margin do accepted rays use?  Exact (binary64) Chebyshev distance from the ray (t >= 0) to
         # the triangle's own bounding box -- a convex piecewise-linear function of t, minimised by ternary search -- over the
         # margin the analysis grants that triangle: 32 (u/eps) P (omax + |v0| + E1 + E2) + 6u (E1 + E2).
@@ -197,5 +268,6 @@ def test_accepted_triangles_pass_their_leafs_culling_box(scene):
         grant = 32 * (uu / float(f32(0.0001))) * (E1 * E2 * 1.25) * (omax + V0 + E1 + E2) + 6 * uu * (E1 + E2)
         worst = max(worst, float((need / grant).max()))
     assert total_acc > 100_000, total_acc
+    assert ancestors_checked > 5 * total_acc or len(nodes) < 64, ancestors_checked
     assert worst < 0.5, worst          # found cases use ~1 % of the margin; anything near the whole of it would question the analysis
     print(f"{scene}: {total_acc} accepted (ray, triangle) pairs, none culled; largest (distance from ray to triangle box) / (margin granted) = {worst:.4f}")

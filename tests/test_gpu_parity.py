@@ -581,7 +581,11 @@ def test_bench_launches_its_own_ranks(sqt):
     for key in ("achieved", "peak", "unit", "frac", "traffic"):
         assert key in roof, key
     assert roof["frac"] is None or 0 < roof["frac"] <= 1                # None: no PMC pass of this (overridden) workload is committed
+    assert "pmc_stale" in roof and j1["build_id"] == sqt.build_id()     # the counters are tied to the library that ran
     assert "roofline" not in j2 and "cpu_baseline" not in j2            # N = 1 figures
+    rk = j2["ranks"]                                                    # what a scaling shortfall would be attributed with
+    assert rk["world_size"] == 2 and rk["backend"] == "gloo"
+    assert 0 < rk["per_rank_ms"][0] <= rk["per_rank_ms"][1] and 0 <= rk["gather_ms"][0] <= rk["gather_ms"][1]
     assert j1["n_gpus"] == 1 and j2["n_gpus"] == 2 and j2["scaling"] == "strong" and "not_a_measurement" in j2
     assert j2["config"]["samples_per_step"] == j1["config"]["samples_per_step"] == 96 * 64 * 8      # the SAME frame, shared
     assert j2["config"]["nonblack_pixels"] == j1["config"]["nonblack_pixels"] > 0                   # and the same image

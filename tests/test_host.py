@@ -250,6 +250,26 @@ def test_debug_show_prints_haskell_show_text(sqt):
     assert sqt.Mesh.from_arrays(tris, m).debug_show() == ("", "")
 
 
+def test_debug_show_escapes_names_like_showLitChar(sqt):
+    """`show :: String` per GHC.Show.showLitChar, on names the reference's `word` token admits (src/Obj.hs:130: anything but
+    " \\t\\n\\r\\f\\v"): control characters by their ASCII names, \\DEL, \\SO guarded by \\& before an H, code points above
+    127 in decimal (the reference's readFile decodes UTF-8 first) guarded by \\& before a digit, backslash and quote."""
+    cases = [("caf\u00e9", 'caf\\233'), ("\u00e91", '\\233\\&1'), ("a\x7fb", 'a\\DELb'), ("x\x0eH", 'x\\SO\\&H'), ("x\x0eI", 'x\\SOI'),
+             ("\x01\x07\x08\x1b\x1f", '\\SOH\\a\\b\\ESC\\US'), ("b\\s", 'b\\\\s'), ("\u4e16\u754c9", '\\19990\\30028\\&9'),
+             ("\U0001f600", '\\128512'), ("plain.Name_1", 'plain.Name_1')]
+    for name, shown in cases:
+        raw = name.encode("utf-8")
+        obj = b"mtllib s.sq\no A\nv 1 2 3\nv 0 1 0\nv 0 0 1\nusemtl " + raw + b"\nf 1 2 3\n"
+        sq = b"newmtl " + raw + b"\nreflective 0 1 1 1\nemissive 0 0 0 0\n"
+        first, mats = sqt.Mesh.from_text(obj, sq).debug_show()
+        assert f'mtl = "{shown}"' in first, (name, first)
+        assert mats.startswith(f'[("{shown}",Mat '), (name, mats)
+    # a byte string that is not UTF-8 (the reference's readFile would throw): each byte as the code point of its value
+    first, _ = sqt.Mesh.from_text(b"mtllib s.sq\no A\nv 1 2 3\nv 0 1 0\nv 0 0 1\nusemtl \xff\xc3\nf 1 2 3\n",
+                                  b"newmtl \xff\xc3\nreflective 0 1 1 1\nemissive 0 0 0 0\n").debug_show()
+    assert 'mtl = "\\255\\195"' in first
+
+
 # ---- independent checks of the host loader and BIH build: nothing below goes through oracle/sq_oracle.c ----
 def _numpy_bih_check(bih_nodes, leaf_tris, mesh_tris):
     """Re-derive makeBIH (src/BIH.hs:62-99) in numpy float32 from the INPUT triangles and walk the product's

@@ -42,6 +42,12 @@ __global__ void __launch_bounds__(256) k(float* out, float a, float b) {
         if (KIND == 24) asm volatile(R8("v_min_f32 %0, %0, %4\n v_max_f32 %1, %1, %4\n v_min_f32 %2, %2, %4\n v_max_f32 %3, %3, %4\n") : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(a));
         if (KIND == 25) asm volatile(R8("v_max3_f32 %0, %0, %4, %1\n v_min3_f32 %1, %1, %4, %2\n v_max3_f32 %2, %2, %4, %3\n v_min3_f32 %3, %3, %4, %0\n") : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(a));
         if (KIND == 26) asm volatile(R8("v_and_b32 %0, %0, %4\n v_add_u32 %1, %1, %4\n v_lshlrev_b32 %2, 4, %2\n v_bfe_u32 %3, %3, 16, 16\n") : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(a));
+        if (KIND == 27) asm volatile(R8("v_mov_b32 %0, %4\n v_mov_b32 %1, %4\n v_mov_b32 %2, %4\n v_mov_b32 %3, %4\n") : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(a));
+        if (KIND == 28) asm volatile(R8("v_fma_mix_f32 %0, %4, %0, %0 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %1, %4, %1, %1 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %2, %4, %2, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %3, %4, %3, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n") : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(a));
+        if (KIND == 29) { unsigned long long y0 = i0, y1 = i1; asm volatile(R8("v_lshl_add_u64 %0, %0, 0, %2\n v_lshl_add_u64 %1, %1, 0, %2\n v_lshl_add_u64 %0, %0, 0, %2\n v_lshl_add_u64 %1, %1, 0, %2\n") : "+v"(y0), "+v"(y1) : "v"(y0)); x0 += (float)(y0 + y1); }
+        if (KIND == 30) asm volatile(R8("v_alignbit_b32 %0, %0, %1, 7\n v_alignbit_b32 %1, %1, %2, 9\n v_alignbit_b32 %2, %2, %3, 11\n v_alignbit_b32 %3, %3, %0, 13\n") : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(a));
+        if (KIND == 31) asm volatile(R8("v_xor_b32 %0, %0, %4\n v_xor_b32 %1, %1, %4\n v_xor_b32 %2, %2, %4\n v_xor_b32 %3, %3, %4\n") : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(a));
+        if (KIND == 32) asm volatile(R8("v_cvt_f32_u32 %0, %0\n v_cvt_f32_u32 %1, %1\n v_cvt_f32_u32 %2, %2\n v_cvt_f32_u32 %3, %3\n") : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(a));
         if (KIND == 17) asm volatile(R8("v_mul_f32 %0, %0, %4\n v_mul_f32 %1, %0, %4\n v_mul_f32 %2, %1, %4\n v_mul_f32 %3, %2, %4\n") : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(a));   // dependent chain
         if (KIND == 18) asm volatile(R8("v_mul_f32 %0, %0, %4\n s_and_saveexec_b64 s[20:21], vcc\n v_mul_f32 %1, %1, %4\n s_or_b64 exec, exec, s[20:21]\n v_mul_f32 %2, %2, %4\n s_and_saveexec_b64 s[20:21], vcc\n v_mul_f32 %3, %3, %4\n s_or_b64 exec, exec, s[20:21]\n") : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(a) : "s20", "s21", "scc", "vcc");
     }
@@ -71,6 +77,12 @@ int main() {
         run<22>("v_cndmask_b32_e32 (no RAW chain)", 32, w); run<23>("v_sub/v_add_f32", 32, w); run<24>("v_min/v_max_f32", 32, w);
         run<25>("v_max3/v_min3_f32", 32, w); run<26>("and/add_u32/lshlrev/bfe mix", 32, w);
         run<16>("ds_read_b128 random + 4 v_mul", 1, w);
+        run<27>("v_mov_b32", 32, w); run<28>("v_fma_mix_f32 (binary16 source)", 32, w); run<29>("v_lshl_add_u64", 32, w);
+        run<30>("v_alignbit_b32", 32, w); run<31>("v_xor_b32", 32, w); run<32>("v_cvt_f32_u32", 32, w);
+    }
+    for (int w : {1, 2, 8}) {   // how the price of the main classes depends on the waves that share a SIMD
+        run<0>("v_mul_f32", 32, w); run<1>("v_fma_f32", 32, w); run<2>("v_cmp_lt_f32 -> sgpr pair", 32, w); run<3>("v_cndmask_b32", 32, w);
+        run<24>("v_min/v_max_f32", 32, w); run<26>("and/add_u32/lshlrev/bfe mix", 32, w); run<27>("v_mov_b32", 32, w);
     }
     return 0;
 }
