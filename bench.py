@@ -37,9 +37,12 @@ CONFIGS = {"c2": (1920, 1080, 256), "c4": (3840, 2160, 1024)}   # first number =
 # SQ_INSTS_VALU_<class> counters give the classes below; the rest of SQ_INSTS_VALU ("other": compares, min/max, selects, moves,
 # DPP, lane reads) has no counter of its own, so it is priced between its cheapest member (v_cndmask / v_mov, 2.5) and its most
 # expensive ones (v_cmp, v_min/max, DPP, v_readlane: 4.3), with the mean of the shipped kernel's static mix as the point value.
-VALU_PRICE = {"ADD_F32": 2.5, "MUL_F32": 2.5, "FMA_F32": 3.7, "TRANS_F32": 8.5, "INT32": 4.2, "INT64": 5.1, "CVT": 4.2,
+# Measured again in round 3 (profiles/r03a_op_rate.txt): v_add/sub 2.50, v_mul 2.5-2.7, v_mov 2.25, v_xor 2.33, v_fma 3.76, v_cmp 4.1-4.35,
+# v_min/max 4.40, v_max3/min3 4.57, integer mix 4.22, v_fma_mix 4.39, v_cvt 4.11, v_lshl_add_u64 6.05, v_rcp 8.54; 1, 2 and 8 waves per
+# SIMD price the 4-cycle classes the same (4.1-4.5), so these are pipeline rates, not a shortage of waves.
+VALU_PRICE = {"ADD_F32": 2.5, "MUL_F32": 2.6, "FMA_F32": 3.8, "TRANS_F32": 8.5, "INT32": 4.2, "INT64": 6.0, "CVT": 4.1,
               "ADD_F64": 4.2, "MUL_F64": 4.2, "FMA_F64": 4.2}
-VALU_PRICE_OTHER = (2.5, 3.5, 4.3)     # low, point, high
+VALU_PRICE_OTHER = (2.3, 3.6, 4.4)     # low (all moves), point, high (all compares / min-max / DPP / lane reads)
 
 
 def valu_mix_weighted(p, secs):
@@ -56,8 +59,8 @@ def valu_mix_weighted(p, secs):
             "fp32_add_mul_fma_share": round((classed["ADD_F32"] + classed["MUL_F32"] + classed["FMA_F32"]) / float(p["SQ_INSTS_VALU"]), 3),
             "unclassed_share": round(other / float(p["SQ_INSTS_VALU"]), 3),
             "formula": "sum over SQ_INSTS_VALU_<class> of count x cycles-per-instruction-per-SIMD (tools/ubench/op_rate.hip, 4 waves per SIMD: "
-                       "add/mul 2.5, fma 3.7, transcendental 8.5, int32 4.2, int64 5.1, cvt/f64 4.2; unclassed = compares, min/max, selects, "
-                       "moves, DPP, lane reads at 2.5 (low) / 3.5 / 4.3 (high)) / (1024 SIMDs x 2.4 GHz x kernel seconds)"}
+                       "add 2.5, mul 2.6, fma 3.8, transcendental 8.5, int32 4.2, int64 6.0, cvt 4.1, f64 4.2; unclassed = compares, min/max, selects, "
+                       "moves, DPP, lane reads at 2.3 (low) / 3.6 / 4.4 (high)) / (1024 SIMDs x 2.4 GHz x kernel seconds)"}
 
 
 def alg_bytes(c, spp):
@@ -105,6 +108,18 @@ def load_profile(name):
         with open(path) as f:
             return json.load(f)
     return None
+
+
+class stdout_to_stderr:
+    """RCCL prints a version banner on STDOUT when a communicator comes up; rank 0's stdout must carry the JSON line only."""
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
 
 
 def launch_ranks(args):
@@ -238,10 +253,12 @@ def scaling_probe(sqt, torch, dist, d, scene, cam, w, h, spp, reps=3):
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             with socket.socket() as sk:
                 sk.bind(("127.0.0.1", 0)); os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
-            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", torch.cuda.current_device()))
+            with stdout_to_stderr():
+                dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", torch.cuda.current_device()))
             created = True
         frame = torch.zeros((w, h, 3), dtype=torch.uint8, device="cuda")
-        d.gather_frame(frame, w)                                       # first call: communicator set-up
+        with stdout_to_stderr():
+            d.gather_frame(frame, w); torch.cuda.synchronize()         # first call: communicator set-up
         out["rccl_all_gather_world1_ms"] = round(timed(lambda: d.gather_frame(frame, w)), 3)
         out["rccl_world_size"] = dist.get_world_size()
         if created:
@@ -264,7 +281,7 @@ def main():
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--spp", type=int, default=0)
     ap.add_argument("--cpu-rows", type=int, default=240, help="rows of the frame timed on the CPU oracle (240 rows = 66 M samples: about 10 s on 16 cores)")
-    ap.add_argument("--other-cpu-rows", type=int, default=2, help="rows of the C3 / C5 stand-in frames timed on the CPU oracle (2 rows at full spp: about 10 s each on 16 cores)")
+    ap.add_argument("--other-cpu-rows", type=int, default=6, help="rows of the C3 / C5 stand-in frames timed on the CPU oracle (6 rows spread over the frame at full spp: 10-20 s each on 16 cores)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-other", action="store_true", help="skip the C3/C5 stand-ins, the C4 frame and the scaling probe (N = 1 only)")
     ap.add_argument("--no-oneshot", action="store_true", help="skip the one-shot call's wall time (profiling runs: keeps the launch count per step)")
@@ -317,10 +334,12 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group("gloo")
+        with stdout_to_stderr():
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group("gloo")
+            dist.barrier()                                    # brings the communicator up (and its banner) before anything is timed
     world = dist.get_world_size() if use_dist else 1          # the ranks RCCL actually connected
 
     data = os.path.join(ROOT, "data")
