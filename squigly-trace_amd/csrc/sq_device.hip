@@ -473,6 +473,9 @@ struct TraceArgs {
     int32_t flush_min;           // pooled form: a trailing part-filled window of the pair pool is run at once from this many pairs on
     int32_t descend_extra, descend_lanes;   // pooled form: further branch steps per iteration for lanes that keep descending, and how many such lanes it takes
     int32_t diag;                // option "coresidency": keep the gauge of live workgroups in stats[24]
+    int32_t prio;                // option "trace_prio": s_setprio level of the trace kernel's waves (0 = leave it), for the overlapped
+                                 //   schedules: per-sample kernels that share a SIMD with a trace workgroup then only get the issue
+                                 //   slots the trace waves leave free
     int32_t pixel_major;         // queue ORDER: 0 = slot order (sample-major: neighbouring pixels, one sample each), 1 = all samples
                                  //   of a pixel in a row, so that a wave's rays start from one surface point (slots stay where they are)
     unsigned long long* stats;   // [0] rays traced; PROFILE builds: [1] advance iterations (waves), [2] lanes unwinding,
@@ -606,12 +609,13 @@ __global__ void __launch_bounds__(BLOCK, RESIDENT ? 1 : SQ_STREAM_MIN_WAVES) sq_
         root_ref = S.rroot;
     } else {
         for (int i = threadIdx.x; i < 3 * A.n_lds; i += BLOCK) { const float4 q = S.branches[i]; lquads[i] = v4f{ q.x, q.y, q.z, q.w }; }
-        N = HybridNodes{ lquads, S.branches, (uint32_t)A.n_lds, S.cull_child, S.cull_child != nullptr, S.cull_child16 };
+        N = HybridNodes{ lquads, S.branches, (uint32_t)A.n_lds, S.cull_child, S.cull_child != nullptr, S.cull_child16, S.incremental_ok != 0 };
         G = GlobalTris{ S.tris, S.leaves, S.packed_leaves != 0, (size_t)S.n_tris * sizeof(DevTri) > ((size_t)4 << 20) };
         root_ref = S.root_ref;
     }
     __syncthreads();
     if (A.diag && threadIdx.x == 0) atomicAdd(&A.stats[kDiagGauge], 1ull);
+    if (A.prio == 1) __builtin_amdgcn_s_setprio(1); else if (A.prio == 2) __builtin_amdgcn_s_setprio(2); else if (A.prio == 3) __builtin_amdgcn_s_setprio(3);
     const long long n_front = A.front ? (long long)(*A.n_active) : 0;
     const long long n = (long long)(*A.n_active) * A.k_count + n_front;          // queue positions; slot_of() maps them to slots
     const unsigned n_pix = (unsigned)(*A.n_active), kq = (unsigned)A.k_count;
@@ -989,7 +993,7 @@ struct sq_device_scene {
     SceneView view{};
     void* d_arena = nullptr;      // every d_* array below lives in this one allocation
     void *d_branches = nullptr, *d_leaves = nullptr, *d_tris = nullptr, *d_mats = nullptr, *d_verts = nullptr, *d_trix = nullptr, *d_rbranch = nullptr, *d_emitters = nullptr, *d_tri_mat = nullptr, *d_surfs = nullptr, *d_cull_child = nullptr, *d_cull16 = nullptr, *d_rtail = nullptr;
-    int height = 0; bool small_index = false; int n_cu = 256;
+    int height = 0; bool small_index = false; int n_cu = 256; int64_t n_grown = 0;
     // workspace (grow-only)
     Work work{}; void* d_work = nullptr; size_t work_bytes = 0; int64_t work_pixels = 0, work_slots = 0;
     // timing of the dominant kernel
@@ -1001,7 +1005,7 @@ struct sq_device_scene {
     // second stream of the overlapped schedule (launch_frame) and its event pool
     hipStream_t aux = nullptr; std::vector<hipEvent_t> events;
     int64_t opt_overlap = 0, opt_aux_blocks_per_cu = 0;
-    int64_t opt_pool = 1, opt_refill_min = 12, opt_flush_min = 40, opt_guided = 1, opt_primary_resident = 1, opt_pixel_major = -1, opt_cull = 1, opt_descend_extra = 2, opt_descend_lanes = 16, opt_primary_pooled = 0, opt_coresidency = 0;
+    int64_t opt_pool = 1, opt_refill_min = 12, opt_flush_min = 40, opt_guided = 1, opt_primary_resident = 1, opt_pixel_major = -1, opt_cull = 1, opt_descend_extra = 2, opt_descend_lanes = 16, opt_primary_pooled = 0, opt_coresidency = 0, opt_incremental = 1, opt_trace_prio = 0, opt_aux_low_priority = 1;
 };
 
 namespace {
@@ -1080,6 +1084,8 @@ extern "C" int sq_scene_upload(const sq_scene* sc, int32_t device, sq_device_sce
     }
     std::vector<DevBranch> br((size_t)nb);
     std::vector<int> br_axis((size_t)nb);
+    std::vector<uint32_t> br_grown((size_t)nb, 0u);     // kGrownLeft | kGrownRight (sq_scene.h), for the incremental slab test
+    bool incremental_ok = true;                         // no child interval is inverted anywhere in the tree
     std::vector<DevLeaf> lf((size_t)nl);
     std::vector<sq_bounds> box((size_t)n);
     box[0] = sc->root;
@@ -1092,6 +1098,11 @@ extern "C" int sq_scene_upload(const sq_scene* sc, int32_t device, sq_device_sce
         for (int c = 0; c < 3; ++c) { d.lo[c] = b.lo[c]; d.hi[c] = b.hi[c]; }
         d.lmax = d.lmax2 = nd.lmax; d.rmin = d.rmin2 = nd.rmin; br_axis[ref[(size_t)i]] = kind;
         d.left = ref[(size_t)i + 1]; d.right = ref[(size_t)nd.link];
+        {   // how the children's planes sit in this branch's interval on the split axis (NaN fails every comparison)
+            const float lo = b.lo[kind], hi = b.hi[kind];
+            if (!(lo <= hi) || !(lo <= nd.lmax) || !(nd.rmin <= hi)) incremental_ok = false;
+            br_grown[ref[(size_t)i]] = (nd.lmax > hi ? kGrownLeft : 0u) | (nd.rmin < lo ? kGrownRight : 0u);
+        }
         sq_bounds l = b, r = b;                          // src/BIH.hs:130-141
         l.hi[kind] = nd.lmax; r.lo[kind] = nd.rmin;
         box[(size_t)i + 1] = l; box[(size_t)nd.link] = r;
@@ -1227,7 +1238,7 @@ extern "C" int sq_scene_upload(const sq_scene* sc, int32_t device, sq_device_sce
         for (int32_t i = 0; i < nb; ++i) {
             DevBranch& d = br[(size_t)i];
             d.left = enc(d.left) | ((uint32_t)br_axis[(size_t)i] << 29);   // kAxisMask bits
-            d.right = enc(d.right);
+            d.right = enc(d.right) | (br_grown[(size_t)i] << 29);          // the same bits of the right word: grown children
         }
         root_ref = enc(root_ref);
     }
@@ -1298,6 +1309,8 @@ extern "C" int sq_scene_upload(const sq_scene* sc, int32_t device, sq_device_sce
     v.rbranch = (const uint32_t*)s->d_rbranch; v.rroot = rroot;
     v.emitters = (const int32_t*)s->d_emitters; v.n_emitters = n_emitters;
     v.cull_o2max = cull_limits[0]; v.cull_d2min = cull_limits[1]; v.cull_d2max = cull_limits[2];
+    v.incremental_ok = (incremental_ok && v.finite_geometry) ? 1 : 0;
+    s->n_grown = 0; for (uint32_t g : br_grown) s->n_grown += (g & 1u) + (g >> 1);
     v.cull_child = (const float4*)s->d_cull_child; v.cull_child16 = (const uint4*)s->d_cull16; v.rtail = (const uint4*)s->d_rtail;
     *out = s;
     return 0;
@@ -1413,6 +1426,7 @@ template <typename StackT>
 int launch_frame(sq_device_scene* s, const Frame& F, hipStream_t stream) {
     SceneView S = s->view;
     if (!s->opt_cull) S.cull_o2max = -1.0f;                            // no ray is inside the culling limits: every leaf is tested
+    if (!s->opt_incremental) S.incremental_ok = 0;                     // every branch step reads the branch's box and tests both children from scratch
     const long long pixels = (long long)F.local_rows * F.h;
     const int stack_cap = std::max(S.height, 1);
     const size_t px_lds = (size_t)kBlock * stack_cap * sizeof(StackT);
@@ -1545,7 +1559,7 @@ int launch_frame(sq_device_scene* s, const Frame& F, hipStream_t stream) {
         TraceArgs A{ W.org, W.dir, W.hit, W.state, level == 0 ? (int32_t)kRay1 : (int32_t)kRay2, (long long)s->work.slot_capacity, with_mirror_rays ? 1 : 0,
                      W.n_active, kc, W.head[level], n_lds, stack_cap, (int32_t)s->opt_straggler, chunk, guide_shift,
                      (int32_t)s->opt_refill_min, (int32_t)s->opt_flush_min, (int32_t)s->opt_descend_extra, (int32_t)s->opt_descend_lanes,
-                     (int32_t)(s->opt_coresidency ? 1 : 0), (int32_t)pixel_major, W.stats };
+                     (int32_t)(s->opt_coresidency ? 1 : 0), (int32_t)s->opt_trace_prio, (int32_t)pixel_major, W.stats };
         return timed([&] {
             void* kargs[] = { (void*)&S, (void*)&A };
             (void)hipLaunchKernel(trace_fn, dim3(trace_blocks), dim3(trace_threads), kargs, tr_lds, on);
@@ -1595,7 +1609,16 @@ int launch_frame(sq_device_scene* s, const Frame& F, hipStream_t stream) {
         }
         return 0;
     }
-    if (!s->aux) SQ_HIP(hipStreamCreateWithFlags(&s->aux, hipStreamNonBlocking));
+    if (!s->aux) {
+        // The second stream carries the per-sample kernels (overlap 1) or the odd batches (overlap 2).  Lowest priority: when a
+        // trace launch and a per-sample kernel become ready together, the trace workgroups (one per CU, all of its LDS) must be
+        // placed first and the per-sample blocks fill the wave slots beside them; the other way round the trace workgroups wait
+        // for whole CUs to drain (rocprofv3 timeline, profiles/r03c_timeline_clocks_coresidency.txt).
+        int least = 0, greatest = 0;
+        SQ_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        if (s->opt_aux_low_priority) SQ_HIP(hipStreamCreateWithPriority(&s->aux, hipStreamNonBlocking, least));    // `least` = numerically largest = lowest priority
+        else SQ_HIP(hipStreamCreateWithFlags(&s->aux, hipStreamNonBlocking));
+    }
     const hipStream_t X = s->aux;
     size_t next_event = 0;
     auto new_event = [&](hipEvent_t* e) -> int {
@@ -1758,6 +1781,13 @@ extern "C" int sq_set_option(sq_device_scene* s, const char* key, int64_t value)
     if (!std::strcmp(key, "cull")) { s->opt_cull = value ? 1 : 0; return 0; }
     if (!std::strcmp(key, "primary_pooled")) { s->opt_primary_pooled = value != 0; return 0; }
     if (!std::strcmp(key, "coresidency")) { s->opt_coresidency = value != 0; return 0; }
+    if (!std::strcmp(key, "incremental")) { s->opt_incremental = value != 0; return 0; }
+    if (!std::strcmp(key, "trace_prio")) { if (value < 0 || value > 3) return sq_set_error("trace_prio must be in 0..3"); s->opt_trace_prio = value; return 0; }
+    if (!std::strcmp(key, "aux_low_priority")) {           // takes effect when the second stream is created (first overlapped frame)
+        s->opt_aux_low_priority = value != 0;
+        if (s->aux) { (void)hipStreamSynchronize(s->aux); (void)hipStreamDestroy(s->aux); s->aux = nullptr; }
+        return 0;
+    }
     if (!std::strcmp(key, "descend_extra")) { if (value < 0 || value > 16) return sq_set_error("descend_extra must be in 0..16"); s->opt_descend_extra = value; return 0; }
     if (!std::strcmp(key, "descend_lanes")) { if (value < 1 || value > 64) return sq_set_error("descend_lanes must be in 1..64"); s->opt_descend_lanes = value; return 0; }
     if (!std::strcmp(key, "pixel_major")) { s->opt_pixel_major = value < 0 ? -1 : value != 0; return 0; }
