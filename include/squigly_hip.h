@@ -99,10 +99,10 @@ void sq_kernel_timing_reset(sq_device_scene* s);
 int  sq_get_stats(sq_device_scene* s, uint64_t* out, int32_t n, int32_t reset);
 /* Tunables; every setting produces identical bits.  Keys:
  *   "variant"            1 = one-lane-per-pixel kernel, 2 = wavefront pipeline (default)
- *   "slots"              sample slots of the frame workspace (default 512 Mi at 61 B each = 33 GB of the
+ *   "slots"              sample slots of the frame workspace (default 512 Mi at 45 B each = 24 GB of the
  *                        288 GB; a frame with fewer samples allocates only what it needs)
  *   "resident"           1 = keep the whole scene in LDS when it fits (default), 0 = always stream
- *   "lds_node_kb"        streaming form: KB of LDS for the top of the tree (default 32)
+ *   "lds_node_kb"        streaming form: KB of LDS for the top of the tree (default 32; the six-wave build takes what its third of the LDS leaves)
  *   "pool"               1 = pooled trace kernel (default): a wave tests the triangles of all its open leaves as a pool of
  *                        (ray, triangle) pairs spread over its 64 lanes; 0 = every lane walks its own leaf
  *   "refill_min"         pooled kernel: idle lanes a wave collects before it fetches new rays (default 12)
@@ -117,7 +117,9 @@ int  sq_get_stats(sq_device_scene* s, uint64_t* out, int32_t n, int32_t reset);
  *                        frame 54.2 -> 54.4 ms; default 0
  *   "guided"             1 = queue reservations shrink towards the end of a launch (default), 0 = fixed size
  *   "straggler_lanes"    pool = 0: lanes still traversing when a wave turns to its leaves (default 8)
- *   "trace_blocks_per_cu" streaming form: workgroups per CU (0 = as many as LDS allows, up to 4)
+ *   "trace_blocks_per_cu" streaming form: 512-thread workgroups per CU.  0 (default) = three, with the kernel compiled for six waves per
+ *                        SIMD (80 VGPRs), when a workgroup's stacks plus at least 4 KB of the tree's top fit in a third of the LDS, else
+ *                        two with the plain build (86 VGPRs, up to lds_node_kb of tree); 1 / 2 = the plain build; 3 = the six-wave build if it fits
  *   "timing"             1 = bracket the dominant kernel with hipEvents for sq_kernel_timing (default 0)
  *   "profile"            1 = lane-occupancy counters in sq_get_stats (slower)
  *   "overlap"            0 = one stream (default; per-kernel durations stay clean for the roofline)

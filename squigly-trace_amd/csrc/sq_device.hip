@@ -169,11 +169,18 @@ struct Work {                 // device workspace of one frame (HBM)
     int32_t* px_mtri;         //   sample of the pixel that mirrors at depth 0 shoots this same ray): t, triangle (-1 = miss)
     // per sample slot sid = k_local * A + a : the ray queue is dense in sid, dead entries are flagged
     uint8_t* state;           // one byte per slot: kDone / kRay1 / kMirror / kRay2.  The trace kernel's refill scan, shade1 and
-                              //   shade2 look at this byte first and touch a slot's 60 other bytes only if they need them
-    float4*  org;             // ray origin.xyz (w unused)
-    float4*  dir;             // ray direction.xyz ; w = triangle hit by ray 1 (second bounce level)
-    int2*    hit;             // (t bits, tri) of the ray currently in the slot
-    uint2*   rng12;           // (n1, n2) of the sample's generator
+                              //   sq_accumulate look at this byte first and touch a slot's 32 other bytes only if they need them
+    // 45 bytes per slot (round 2: 61).  A slot's two quads are reused as the sample moves on:
+    //   org : ray origin.xyz while the ray waits in the queue; the trace kernel puts the ray's HIT into .xy (t bits, triangle)
+    //         when it is done with it -- nothing reads an origin after that (ray 1 starts at the pixel's primary hit point, which
+    //         sq_shade1 recomputes).  .w = n1 of the sample's generator until sq_shade1 has used it; a kMirror slot, which holds
+    //         no ray of its own, keeps n2 in .z as well.
+    //   dir : ray direction.xyz.  .w = n2 of the generator (first bounce level), then the triangle hit by ray 1 (second level).
+    // The radiance of a finished sample keeps an array of its own: folded into the origin quad as well (33 bytes per slot) the
+    // frame measured 0.4 ms slower -- sq_accumulate and sq_shade1 are bound by the bytes they move, and 16-byte records carry
+    // 12 bytes of radiance (profiles/r03f_slots_ab.txt).
+    float4*  org;
+    float4*  dir;
     float*   rad;             // finished sample radiance, 3 floats
     int32_t* head[2];         // dequeue cursors of the persistent trace kernel, one per bounce level
     unsigned long long* stats;  // cumulative trace-kernel statistics (TraceArgs::stats)
@@ -245,6 +252,7 @@ __device__ __forceinline__ bool absorbs(const SceneView& S, const Surface& s) {
 __device__ __forceinline__ void store_rad(const Work& W, long long sid, f3 L) {
     W.rad[3 * sid] = L.x; W.rad[3 * sid + 1] = L.y; W.rad[3 * sid + 2] = L.z;
 }
+__device__ __forceinline__ int2 slot_hit(const float4& org) { return make_int2(__float_as_int(org.x), __float_as_int(org.y)); }   // what the trace kernel left in org.xy
 
 // Depth-0 bounce of every sample of the batch: RNG, bounceRay, ray 1 into slot sid (src/Lib.hs:133-134).
 // One thread per active pixel (blockIdx.y splits the samples of a pixel when a frame has few pixels): everything that is
@@ -271,15 +279,15 @@ __global__ void __launch_bounds__(kBlock) sq_gen_bounce1(const SceneView S, cons
 #else
             sq::tfgen3(rix + (k_base + kl), n0, n1, n2);                // mkTFGen (rix + k), src/Lib.hs:86
 #endif
-            W.rng12[sid] = make_uint2(n1, n2);
-            if (!scatters(P.s0, n0)) {                                  // mirror: traced once per pixel (sq_mirror1_*)
+            if (!scatters(P.s0, n0)) {                                  // mirror: traced once per pixel (sq_mirror1_*); the slot only carries n1, n2
                 W.state[sid] = kMirror;
+                *reinterpret_cast<float2*>(reinterpret_cast<float*>(W.org + sid) + 2) = make_float2(__uint_as_float(n2), __uint_as_float(n1));   // .z = n2, .w = n1
                 continue;
             }
             const f3 d1 = scatter_dir(P.d0, P.s0, n0, n1);
             W.state[sid] = kRay1;
-            W.org[sid] = make_float4(P.p0.x, P.p0.y, P.p0.z, 0.0f);
-            W.dir[sid] = make_float4(d1.x, d1.y, d1.z, 0.0f);
+            W.org[sid] = make_float4(P.p0.x, P.p0.y, P.p0.z, __uint_as_float(n1));
+            W.dir[sid] = make_float4(d1.x, d1.y, d1.z, __uint_as_float(n2));
         }
     }
     diag_aux_wave(W, F.diag, false);
@@ -304,7 +312,7 @@ __global__ void __launch_bounds__(kBlock) sq_mirror1_store(const Work W, long lo
     const int A = *W.n_active;
     for (int a = blockIdx.x * kBlock + threadIdx.x; a < A; a += gridDim.x * kBlock) {
         const bool live = W.state[base + a] == kRay1;
-        const int2 hit = W.hit[base + a];
+        const int2 hit = slot_hit(W.org[base + a]);
         W.px_mt[a] = live ? __int_as_float(hit.x) : 0.0f;
         W.px_mtri[a] = live ? hit.y : -1;
     }
@@ -328,7 +336,7 @@ __global__ void __launch_bounds__(kBlock) sq_primary_store(const Work W, long lo
     for (long long base = (long long)blockIdx.x * kBlock; base < total; base += (long long)gridDim.x * kBlock) {   // whole waves stay together (ballot)
         const long long pix = base + threadIdx.x;
         const bool in = pix < total;
-        const int2 hit = in ? W.hit[pix] : make_int2(0, -1);
+        const int2 hit = in ? slot_hit(W.org[pix]) : make_int2(0, -1);
         const int a = wave_append(W.n_active, in && hit.y >= 0);
         if (a >= 0) {
             W.px_pixel[a] = (int32_t)pix; W.px_t0[a] = __int_as_float(hit.x); W.px_tri0[a] = hit.y;
@@ -345,18 +353,18 @@ __global__ void __launch_bounds__(kBlock) sq_primary_store(const Work W, long lo
 __global__ void __launch_bounds__(kBlock) sq_shade1(const SceneView S, const Frame F, const Work W, int k_count) {
     const int A = *W.n_active;
     diag_aux_wave(W, F.diag, true);
-    struct First { uint8_t st; uint2 r; };
-    struct Second { float4 dir; int2 hit; };      // ray 1 starts at the pixel's primary hit point P.p0 (sq_gen_bounce1 stored that very value): org is not re-read
+    struct First { uint8_t st; float4 org; };     // org: .xy = the hit the trace kernel left (traced slots), .w = n1
+    struct Second { float4 dir; };                // .w = n2.  Ray 1 starts at the pixel's primary hit point P.p0 (sq_gen_bounce1 stored that very value): no origin is re-read
     for (int a = blockIdx.x * kBlock + threadIdx.x; a < A; a += gridDim.x * kBlock) {
         const Pixel0 P = load_pixel0(S, F, W, a);
         const Surface& s0 = P.s0;
         const f3 d1_mirror = mirror_dir(P.d0, P.s0);
         const int2 hit_mirror = make_int2(__float_as_int(W.px_mt[a]), W.px_mtri[a]);
         const int step = gridDim.y;
-        auto first = [&](int kl) { First f; const long long sid = (long long)kl * A + a; f.st = W.state[sid]; f.r = W.rng12[sid]; return f; };
+        auto first = [&](int kl) { First f; const long long sid = (long long)kl * A + a; f.st = W.state[sid]; f.org = W.org[sid]; return f; };
         auto second = [&](int kl, uint8_t st) {
             Second q{};
-            if (st == kRay1) { const long long sid = (long long)kl * A + a; q.dir = W.dir[sid]; q.hit = W.hit[sid]; }
+            if (st == kRay1) { const long long sid = (long long)kl * A + a; q.dir = W.dir[sid]; }
             return q;
         };
         int kl = blockIdx.y;
@@ -370,11 +378,11 @@ __global__ void __launch_bounds__(kBlock) sq_shade1(const SceneView S, const Fra
             if (kl + 2 * step < k_count) f2 = first(kl + 2 * step);
             if (cur.st == kDone) continue;
             const long long sid = (long long)kl * A + a;
-            const uint2 r = cur.r;
+            const uint2 r = make_uint2(__float_as_uint(cur.org.w), __float_as_uint(cur.st == kMirror ? cur.org.z : q.dir.w));   // (n1, n2)
             f3 d1, p0;
             int2 hit;
             if (cur.st == kMirror) { d1 = d1_mirror; p0 = P.p0; hit = hit_mirror; }          // the pixel's mirror ray and its hit
-            else { d1 = sq::mk(q.dir.x, q.dir.y, q.dir.z); p0 = P.p0; hit = q.hit; }
+            else { d1 = sq::mk(q.dir.x, q.dir.y, q.dir.z); p0 = P.p0; hit = slot_hit(cur.org); }
             const int tri1 = hit.y;
             if (tri1 < 0) {                                             // raytrace ... 1 = black
                 store_rad(W, sid, s0.surf * sq::mk(0, 0, 0) + s0.emit);
@@ -422,7 +430,7 @@ __global__ void __launch_bounds__(kBlock) sq_shade1(const SceneView S, const Fra
 // Not a kernel of its own: the 8 % of the slots that still hold a second bounce ray are folded where their radiance is
 // consumed (sq_accumulate), which saves a pass over every slot's state and the round trip of their radiance through HBM.
 __device__ __forceinline__ f3 shade2_radiance(const SceneView& S, const Work& W, long long sid, const Surface& s0) {
-    const int tri1 = __float_as_int(W.dir[sid].w), tri2 = W.hit[sid].y;
+    const int tri1 = reinterpret_cast<const int*>(W.dir + sid)[3], tri2 = reinterpret_cast<const int*>(W.org + sid)[1];   // dir.w, and the hit's triangle in org.y: 4 bytes each
     f3 L2 = sq::mk(0, 0, 0);
     if (tri2 >= 0) { const Surface s2 = surface_of(S, tri2); L2 = s2.surf * sq::mk(0, 0, 0) + s2.emit; }
     const Surface s1 = surface_of(S, tri1);
@@ -459,7 +467,7 @@ __global__ void __launch_bounds__(kBlock) sq_accumulate(const SceneView S, const
 // branches (breadth-first = the top of the tree) are staged in LDS once per workgroup; every lane
 // keeps its frame stack in LDS (lane-minor layout, one word per frame, at most height-1 frames).
 struct TraceArgs {
-    const float4* org; const float4* dir; int2* hits;
+    float4* org; const float4* dir;          // a finished ray's hit (t bits, triangle) goes into org[slot].xy
     const uint8_t* state; int32_t want;      // a slot is in this launch's queue iff state[slot] == want (kRay1 / kRay2)
     long long front_base; int32_t front;     // front != 0: the queue starts with *n_active extra entries, the slots
                                              //   front_base + [0, *n_active) (the per-pixel mirror rays ride at the head of the
@@ -588,11 +596,8 @@ __global__ void __launch_bounds__(kResidentBlock) sq_primary_resident(const Scen
     }
 }
 
-#ifndef SQ_STREAM_MIN_WAVES
-#define SQ_STREAM_MIN_WAVES 1      // experiment: 6 = register budget for three 512-thread workgroups per CU in the streaming form
-#endif
 template <typename StackT, bool RESIDENT, int BLOCK, bool PROFILE, bool POOL>
-__global__ void __launch_bounds__(BLOCK, RESIDENT ? 1 : SQ_STREAM_MIN_WAVES) sq_trace_rays(const SceneView S, const TraceArgs A) {
+__device__ __forceinline__ void trace_rays_body(const SceneView& S, const TraceArgs& A) {
     extern __shared__ float4 lds_raw[];
     char* lds = reinterpret_cast<char*>(lds_raw);
     const TraceLds L = trace_lds_layout(A.n_lds, RESIDENT, S.n_verts, S.n_tris, BLOCK, A.stack_cap, (int)sizeof(StackT), POOL);
@@ -609,7 +614,7 @@ __global__ void __launch_bounds__(BLOCK, RESIDENT ? 1 : SQ_STREAM_MIN_WAVES) sq_
         root_ref = S.rroot;
     } else {
         for (int i = threadIdx.x; i < 3 * A.n_lds; i += BLOCK) { const float4 q = S.branches[i]; lquads[i] = v4f{ q.x, q.y, q.z, q.w }; }
-        N = HybridNodes{ lquads, S.branches, (uint32_t)A.n_lds, S.cull_child, S.cull_child != nullptr, S.cull_child16, S.incremental_ok != 0 };
+        N = HybridNodes{ lquads, S.branches, (uint32_t)A.n_lds, S.cull_child, S.cull_child != nullptr, S.cull_child16 };
         G = GlobalTris{ S.tris, S.leaves, S.packed_leaves != 0, (size_t)S.n_tris * sizeof(DevTri) > ((size_t)4 << 20) };
         root_ref = S.root_ref;
     }
@@ -708,7 +713,7 @@ __global__ void __launch_bounds__(BLOCK, RESIDENT ? 1 : SQ_STREAM_MIN_WAVES) sq_
         for (;;) {
             if (PROFILE) ++pf_adv;
             const bool idle = (T.mode == M_DONE);
-            if (idle && my_ray >= 0) { A.hits[my_ray] = make_int2(__float_as_int(T.R.t), T.R.tri); my_ray = -1; }
+            if (idle && my_ray >= 0) { *reinterpret_cast<int2*>(A.org + my_ray) = make_int2(__float_as_int(T.R.t), T.R.tri); my_ray = -1; }
             const unsigned long long m = __ballot(idle);
             if (m) {
                 if (__popcll(m) >= A.refill_min || m == ~0ull) refill(m, idle);
@@ -917,7 +922,7 @@ __global__ void __launch_bounds__(BLOCK, RESIDENT ? 1 : SQ_STREAM_MIN_WAVES) sq_
     for (;;) {
         if (PROFILE) ++pf_outer;
         const bool idle = (T.mode == M_DONE);
-        if (idle && my_ray >= 0) { A.hits[my_ray] = make_int2(__float_as_int(T.R.t), T.R.tri); my_ray = -1; }
+        if (idle && my_ray >= 0) { *reinterpret_cast<int2*>(A.org + my_ray) = make_int2(__float_as_int(T.R.t), T.R.tri); my_ray = -1; }
         const unsigned long long m = __ballot(idle);
         if (m) {
             refill(m, idle);
@@ -947,6 +952,20 @@ __global__ void __launch_bounds__(BLOCK, RESIDENT ? 1 : SQ_STREAM_MIN_WAVES) sq_
         atomicAdd(&A.stats[2], (unsigned long long)pl_unw); atomicAdd(&A.stats[3], (unsigned long long)pl_desc);
         atomicAdd(&A.stats[5], (unsigned long long)pl_tri); atomicAdd(&A.stats[8], (unsigned long long)pl_ref);
     }
+}
+
+template <typename StackT, bool RESIDENT, int BLOCK, bool PROFILE, bool POOL>
+__global__ void __launch_bounds__(BLOCK) sq_trace_rays(const SceneView S, const TraceArgs A) {
+    trace_rays_body<StackT, RESIDENT, BLOCK, PROFILE, POOL>(S, A);
+}
+// The streaming pooled kernel once more, compiled for SIX waves per SIMD (at most 80 VGPRs; the plain build takes 86, i.e. four):
+// three 512-thread workgroups per CU instead of two when their stacks and a share of the tree's top fit in a third of the LDS.
+// The streaming form waits on memory two thirds of its time, and the extra waves are worth more than the handful of spilled
+// registers and the smaller LDS node prefix: 25.9 -> 24.5 ms (82k triangles), 30.7 -> 29.4 ms (1M triangles) at 64 spp, same
+// call (profiles/r03c_stream_incremental.txt, rows libc16 / libw6c16 with incremental = 0).
+template <typename StackT>
+__global__ void __launch_bounds__(kTraceBlock, 6) sq_trace_rays_dense(const SceneView S, const TraceArgs A) {
+    trace_rays_body<StackT, false, kTraceBlock, false, true>(S, A);
 }
 
 // ---- diagnostics: primitives of the numeric spec evaluated on the device ----
@@ -993,7 +1012,7 @@ struct sq_device_scene {
     SceneView view{};
     void* d_arena = nullptr;      // every d_* array below lives in this one allocation
     void *d_branches = nullptr, *d_leaves = nullptr, *d_tris = nullptr, *d_mats = nullptr, *d_verts = nullptr, *d_trix = nullptr, *d_rbranch = nullptr, *d_emitters = nullptr, *d_tri_mat = nullptr, *d_surfs = nullptr, *d_cull_child = nullptr, *d_cull16 = nullptr, *d_rtail = nullptr;
-    int height = 0; bool small_index = false; int n_cu = 256; int64_t n_grown = 0;
+    int height = 0; bool small_index = false; int n_cu = 256;
     // workspace (grow-only)
     Work work{}; void* d_work = nullptr; size_t work_bytes = 0; int64_t work_pixels = 0, work_slots = 0;
     // timing of the dominant kernel
@@ -1005,7 +1024,7 @@ struct sq_device_scene {
     // second stream of the overlapped schedule (launch_frame) and its event pool
     hipStream_t aux = nullptr; std::vector<hipEvent_t> events;
     int64_t opt_overlap = 0, opt_aux_blocks_per_cu = 0;
-    int64_t opt_pool = 1, opt_refill_min = 12, opt_flush_min = 40, opt_guided = 1, opt_primary_resident = 1, opt_pixel_major = -1, opt_cull = 1, opt_descend_extra = 2, opt_descend_lanes = 16, opt_primary_pooled = 0, opt_coresidency = 0, opt_incremental = 1, opt_trace_prio = 0, opt_aux_low_priority = 1;
+    int64_t opt_pool = 1, opt_refill_min = 12, opt_flush_min = 40, opt_guided = 1, opt_primary_resident = 1, opt_pixel_major = -1, opt_cull = 1, opt_descend_extra = 2, opt_descend_lanes = 16, opt_primary_pooled = 0, opt_coresidency = 0, opt_trace_prio = 0, opt_aux_low_priority = 1, opt_aux_polite = 0;
 };
 
 namespace {
@@ -1084,8 +1103,6 @@ extern "C" int sq_scene_upload(const sq_scene* sc, int32_t device, sq_device_sce
     }
     std::vector<DevBranch> br((size_t)nb);
     std::vector<int> br_axis((size_t)nb);
-    std::vector<uint32_t> br_grown((size_t)nb, 0u);     // kGrownLeft | kGrownRight (sq_scene.h), for the incremental slab test
-    bool incremental_ok = true;                         // no child interval is inverted anywhere in the tree
     std::vector<DevLeaf> lf((size_t)nl);
     std::vector<sq_bounds> box((size_t)n);
     box[0] = sc->root;
@@ -1098,11 +1115,6 @@ extern "C" int sq_scene_upload(const sq_scene* sc, int32_t device, sq_device_sce
         for (int c = 0; c < 3; ++c) { d.lo[c] = b.lo[c]; d.hi[c] = b.hi[c]; }
         d.lmax = d.lmax2 = nd.lmax; d.rmin = d.rmin2 = nd.rmin; br_axis[ref[(size_t)i]] = kind;
         d.left = ref[(size_t)i + 1]; d.right = ref[(size_t)nd.link];
-        {   // how the children's planes sit in this branch's interval on the split axis (NaN fails every comparison)
-            const float lo = b.lo[kind], hi = b.hi[kind];
-            if (!(lo <= hi) || !(lo <= nd.lmax) || !(nd.rmin <= hi)) incremental_ok = false;
-            br_grown[ref[(size_t)i]] = (nd.lmax > hi ? kGrownLeft : 0u) | (nd.rmin < lo ? kGrownRight : 0u);
-        }
         sq_bounds l = b, r = b;                          // src/BIH.hs:130-141
         l.hi[kind] = nd.lmax; r.lo[kind] = nd.rmin;
         box[(size_t)i + 1] = l; box[(size_t)nd.link] = r;
@@ -1238,7 +1250,7 @@ extern "C" int sq_scene_upload(const sq_scene* sc, int32_t device, sq_device_sce
         for (int32_t i = 0; i < nb; ++i) {
             DevBranch& d = br[(size_t)i];
             d.left = enc(d.left) | ((uint32_t)br_axis[(size_t)i] << 29);   // kAxisMask bits
-            d.right = enc(d.right) | (br_grown[(size_t)i] << 29);          // the same bits of the right word: grown children
+            d.right = enc(d.right);
         }
         root_ref = enc(root_ref);
     }
@@ -1309,8 +1321,6 @@ extern "C" int sq_scene_upload(const sq_scene* sc, int32_t device, sq_device_sce
     v.rbranch = (const uint32_t*)s->d_rbranch; v.rroot = rroot;
     v.emitters = (const int32_t*)s->d_emitters; v.n_emitters = n_emitters;
     v.cull_o2max = cull_limits[0]; v.cull_d2min = cull_limits[1]; v.cull_d2max = cull_limits[2];
-    v.incremental_ok = (incremental_ok && v.finite_geometry) ? 1 : 0;
-    s->n_grown = 0; for (uint32_t g : br_grown) s->n_grown += (g & 1u) + (g >> 1);
     v.cull_child = (const float4*)s->d_cull_child; v.cull_child16 = (const uint4*)s->d_cull16; v.rtail = (const uint4*)s->d_rtail;
     *out = s;
     return 0;
@@ -1385,19 +1395,18 @@ int ensure_workspace(sq_device_scene* s, int64_t pixels, int64_t slots) {
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     if (s->d_work) { cache_give(s->device, s->d_work, s->work_bytes); s->d_work = nullptr; s->work_pixels = s->work_slots = 0; }
     size_t block_bytes = 0;
-    size_t off = 0, o_cnt = 0, o_stats = 0, o_pix = 0, o_t0 = 0, o_tri0 = 0, o_sum = 0, o_mt = 0, o_mtri = 0, o_state = 0, o_org = 0, o_dir = 0, o_hit = 0, o_rng = 0, o_rad = 0;
+    size_t off = 0, o_cnt = 0, o_stats = 0, o_pix = 0, o_t0 = 0, o_tri0 = 0, o_sum = 0, o_mt = 0, o_mtri = 0, o_state = 0, o_org = 0, o_dir = 0, o_rad = 0;
     for (;;) {
         off = 0;
         auto take = [&](size_t bytes) { size_t o = off; off += al(bytes); return o; };
         o_cnt = take(128 * sizeof(int32_t)); o_stats = take(kStatSlots * sizeof(unsigned long long));
         o_pix = take(pixels * 4); o_t0 = take(pixels * 4); o_tri0 = take(pixels * 4); o_sum = take(pixels * 12);
         o_mt = take(pixels * 4); o_mtri = take(pixels * 4);
-        // + pixels: the mirror rays' spare region behind the sample slots (state, ray and hit only)
-        o_state = take(slots + pixels); o_org = take((slots + pixels) * 16); o_dir = take((slots + pixels) * 16);
-        o_hit = take((slots + pixels) * 8); o_rng = take(slots * 8); o_rad = take(slots * 12);
+        // + pixels: the mirror rays' spare region behind the sample slots (state and the two ray quads)
+        o_state = take(slots + pixels); o_org = take((slots + pixels) * 16); o_dir = take((slots + pixels) * 16); o_rad = take(slots * 12);
         // every array has its own, ordered place in the block: a slip here would be a GPU fault, not an error code
         if (!(o_cnt < o_stats && o_stats < o_pix && o_pix < o_t0 && o_t0 < o_tri0 && o_tri0 < o_sum && o_sum < o_mt && o_mt < o_mtri &&
-              o_mtri < o_state && o_state < o_org && o_org < o_dir && o_dir < o_hit && o_hit < o_rng && o_rng < o_rad && o_rad < off))
+              o_mtri < o_state && o_state < o_org && o_org < o_dir && o_dir < o_rad && o_rad < off))
             return sq_set_error("internal error: frame workspace layout");
         block_bytes = off;
         if ((s->d_work = cache_take(s->device, off, &block_bytes)) != nullptr) break;
@@ -1415,8 +1424,7 @@ int ensure_workspace(sq_device_scene* s, int64_t pixels, int64_t slots) {
     if (hipMemset(W.stats, 0, kStatSlots * sizeof(unsigned long long)) != hipSuccess) return sq_set_error("hipMemset failed");
     W.px_pixel = (int32_t*)(base + o_pix); W.px_t0 = (float*)(base + o_t0); W.px_tri0 = (int32_t*)(base + o_tri0); W.px_sum = (float*)(base + o_sum);
     W.px_mt = (float*)(base + o_mt); W.px_mtri = (int32_t*)(base + o_mtri);
-    W.state = (uint8_t*)(base + o_state); W.org = (float4*)(base + o_org); W.dir = (float4*)(base + o_dir); W.hit = (int2*)(base + o_hit);
-    W.rng12 = (uint2*)(base + o_rng); W.rad = (float*)(base + o_rad);
+    W.state = (uint8_t*)(base + o_state); W.org = (float4*)(base + o_org); W.dir = (float4*)(base + o_dir); W.rad = (float*)(base + o_rad);
     W.slot_capacity = slots;
     s->work_bytes = block_bytes; s->work_pixels = pixels; s->work_slots = slots;
     return 0;
@@ -1426,7 +1434,6 @@ template <typename StackT>
 int launch_frame(sq_device_scene* s, const Frame& F, hipStream_t stream) {
     SceneView S = s->view;
     if (!s->opt_cull) S.cull_o2max = -1.0f;                            // no ray is inside the culling limits: every leaf is tested
-    if (!s->opt_incremental) S.incremental_ok = 0;                     // every branch step reads the branch's box and tests both children from scratch
     const long long pixels = (long long)F.local_rows * F.h;
     const int stack_cap = std::max(S.height, 1);
     const size_t px_lds = (size_t)kBlock * stack_cap * sizeof(StackT);
@@ -1466,7 +1473,7 @@ int launch_frame(sq_device_scene* s, const Frame& F, hipStream_t stream) {
     Work Wt[2] = { W, W };
     if (overlap) {
         Work& V = Wt[1];
-        V.state += track_slots; V.org += track_slots; V.dir += track_slots; V.hit += track_slots; V.rng12 += track_slots; V.rad += 3 * track_slots;
+        V.state += track_slots; V.org += track_slots; V.dir += track_slots; V.rad += 3 * track_slots;
         V.head[0] = W.n_active + 64 + 16; V.head[1] = W.n_active + 64 + 32;
     }
     // samples per batch: as many as a track holds, split evenly (few large launches: a small trace launch
@@ -1496,13 +1503,30 @@ int launch_frame(sq_device_scene* s, const Frame& F, hipStream_t stream) {
         trace_blocks = s->n_cu; trace_threads = kResidentBlock;
     } else {
         const size_t max_node_bytes = (size_t)s->opt_lds_node_kb * 1024;     // top of the tree; the rest of LDS buys occupancy
-        if ((size_t)n_lds * 48 > max_node_bytes) n_lds = (int)(max_node_bytes / 48);
+        const int n_lds_want = (int)std::min<size_t>((size_t)S.n_branches, max_node_bytes / 48);
+        const TraceLds L0 = trace_lds_layout(0, false, S.n_verts, S.n_tris, kTraceBlock, stack_cap, (int)sizeof(StackT), pool);   // stacks, live lists, window tables
+        if (L0.total > lds_budget) return sq_set_error("BIH height %d needs %u B of LDS per workgroup (max %zu)", S.height, L0.total, lds_budget);
+        // Three workgroups per CU (the six-wave build) when a third of the LDS holds a workgroup's stacks plus at least 4 KB of
+        // the tree's top (or all of it); otherwise two, or one, with up to lds_node_kb of tree each.
+        const size_t third = (lds_budget / 3) & ~(size_t)2047;            // 52 KB: the hardware allocates LDS in granules, and 3 x 53.3 KB rounded up does not fit
+        const bool dense_fits = L0.total + std::min<size_t>((size_t)S.n_branches * 48, 4096) + 16 <= third;
+        const bool dense = pool && !s->opt_profile && (s->opt_trace_blocks_per_cu == 0 ? dense_fits : s->opt_trace_blocks_per_cu == 3 && dense_fits);
+        int per_cu;
+        if (dense) {
+            per_cu = 3;
+            n_lds = (int)std::min<size_t>((size_t)n_lds_want, (third - L0.total - 16) / 48);
+        } else {
+            n_lds = n_lds_want;
+            while (n_lds > 0 && trace_lds_layout(n_lds, false, S.n_verts, S.n_tris, kTraceBlock, stack_cap, (int)sizeof(StackT), pool).total > lds_budget) n_lds /= 2;
+        }
         L = trace_lds_layout(n_lds, false, S.n_verts, S.n_tris, kTraceBlock, stack_cap, (int)sizeof(StackT), pool);
-        if (L.total > lds_budget) return sq_set_error("BIH height %d needs %u B of LDS per workgroup (max %zu)", S.height, L.total, lds_budget);
-        trace_fn = pool ? (s->opt_profile ? (const void*)sq_trace_rays<StackT, false, kTraceBlock, true, true> : (const void*)sq_trace_rays<StackT, false, kTraceBlock, false, true>)
+        if (!dense) {
+            per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, lds_budget / L.total));    // the plain build's 86 VGPRs allow four waves per SIMD = two workgroups
+            if (s->opt_trace_blocks_per_cu > 0) per_cu = (int)std::min<int64_t>(s->opt_trace_blocks_per_cu, (int64_t)std::max<size_t>(1, lds_budget / L.total));
+        }
+        trace_fn = dense ? (const void*)sq_trace_rays_dense<StackT>
+                 : pool ? (s->opt_profile ? (const void*)sq_trace_rays<StackT, false, kTraceBlock, true, true> : (const void*)sq_trace_rays<StackT, false, kTraceBlock, false, true>)
                         : (s->opt_profile ? (const void*)sq_trace_rays<StackT, false, kTraceBlock, true, false> : (const void*)sq_trace_rays<StackT, false, kTraceBlock, false, false>);
-        int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, lds_budget / L.total));
-        if (s->opt_trace_blocks_per_cu > 0) per_cu = (int)s->opt_trace_blocks_per_cu;
         trace_blocks = s->n_cu * per_cu; trace_threads = kTraceBlock;
     }
     const size_t tr_lds = L.total;
@@ -1540,6 +1564,10 @@ int launch_frame(sq_device_scene* s, const Frame& F, hipStream_t stream) {
     // per-sample kernels that run one thread per active pixel: x covers the pixels, y splits a pixel's samples when the
     // frame has too few pixels to fill the chip (one rank's share of a frame, small frames)
     auto pp_grid = [&](int kc) {
+        // Overlapped schedules, option "aux_polite" = n > 0: the per-sample kernels get n workgroups per CU in all (grid-stride
+        // loops do the rest), few enough that a trace workgroup -- 16 waves, all of the CU's LDS, 4 x 104 VGPRs per SIMD -- can
+        // always be placed beside them, whichever kernel reaches a CU first.
+        if (overlap && s->opt_aux_polite > 0) return dim3((unsigned)(s->n_cu * (int)s->opt_aux_polite), 1u);
         const long long bx = std::max<long long>(1, std::min<long long>((pixels + kBlock - 1) / kBlock, 1 << 20));
         const long long want_threads = (long long)s->n_cu * 2048 * 2;
         const long long ks = std::max<long long>(1, std::min<long long>(std::min(kc, 64), (want_threads + pixels - 1) / std::max<long long>(pixels, 1)));
@@ -1556,7 +1584,7 @@ int launch_frame(sq_device_scene* s, const Frame& F, hipStream_t stream) {
         int guide_shift = 2;                                            // log2(4 x waves of the launch), rounded up
         while ((1ll << guide_shift) < 4ll * trace_blocks * (trace_threads / 64)) ++guide_shift;
         if (!s->opt_guided) guide_shift = 62;
-        TraceArgs A{ W.org, W.dir, W.hit, W.state, level == 0 ? (int32_t)kRay1 : (int32_t)kRay2, (long long)s->work.slot_capacity, with_mirror_rays ? 1 : 0,
+        TraceArgs A{ W.org, W.dir, W.state, level == 0 ? (int32_t)kRay1 : (int32_t)kRay2, (long long)s->work.slot_capacity, with_mirror_rays ? 1 : 0,
                      W.n_active, kc, W.head[level], n_lds, stack_cap, (int32_t)s->opt_straggler, chunk, guide_shift,
                      (int32_t)s->opt_refill_min, (int32_t)s->opt_flush_min, (int32_t)s->opt_descend_extra, (int32_t)s->opt_descend_lanes,
                      (int32_t)(s->opt_coresidency ? 1 : 0), (int32_t)s->opt_trace_prio, (int32_t)pixel_major, W.stats };
@@ -1781,7 +1809,7 @@ extern "C" int sq_set_option(sq_device_scene* s, const char* key, int64_t value)
     if (!std::strcmp(key, "cull")) { s->opt_cull = value ? 1 : 0; return 0; }
     if (!std::strcmp(key, "primary_pooled")) { s->opt_primary_pooled = value != 0; return 0; }
     if (!std::strcmp(key, "coresidency")) { s->opt_coresidency = value != 0; return 0; }
-    if (!std::strcmp(key, "incremental")) { s->opt_incremental = value != 0; return 0; }
+    if (!std::strcmp(key, "aux_polite")) { if (value < 0 || value > 8) return sq_set_error("aux_polite must be in 0..8"); s->opt_aux_polite = value; return 0; }
     if (!std::strcmp(key, "trace_prio")) { if (value < 0 || value > 3) return sq_set_error("trace_prio must be in 0..3"); s->opt_trace_prio = value; return 0; }
     if (!std::strcmp(key, "aux_low_priority")) {           // takes effect when the second stream is created (first overlapped frame)
         s->opt_aux_low_priority = value != 0;

@@ -71,8 +71,6 @@ struct SceneView {
     const float4* cull_child; // streaming form: 4 quads per branch, the culling boxes (lo, hi) of its left and of its right child; or nullptr
     const uint4* rtail;       // resident form: (lmax, rmin, left word, right word) per branch, what a return into a branch needs
     const uint4* cull_child16; // 2 quads per branch, the same boxes as binary16 pairs (x, y, z, unused), left child then right; or nullptr
-    int32_t incremental_ok;    // 1: every child interval of the tree is regular or grown (kGrownLeft / kGrownRight) and the geometry is
-                               // finite: the streaming forms may carry (tmin, tmax) down the tree (trav_descend)
 };
 
 struct Hit { float t; int32_t tri; };   // tri < 0 : Nothing.  dist is derived from t on demand (hit_dist)
@@ -293,17 +291,11 @@ template <> struct StackTraits<uint32_t> { static constexpr uint32_t flag = 0x80
 // kLeafBit; the triangle source of the same kernel knows how to turn a leaf reference into a range.
 struct BranchData { v4f q0, q1; int axis; uint32_t left, right; };   // q0 = lo.xyz,lmax ; q1 = hi.xyz,rmin
 
-struct BranchTail { float lmax, rmin; int axis; uint32_t left, right; uint32_t grown; };   // what a return into a branch needs
+struct BranchTail { float lmax, rmin; int axis; uint32_t left, right; };   // what a return into a branch needs
 constexpr uint32_t kAxisMask = 0x60000000u;     // bits 30..29 of a branch's LEFT reference word: the split axis
-// Bits 30..29 of the RIGHT reference word (streaming forms): "the left / the right child's box GROWS", i.e. the plane that
-// replaces one of this branch's own (lmax for hi[axis], rmin for lo[axis], src/BIH.hs:130-141) lies outside this branch's box,
-// which happens where lmax = max + 0.001 or rmin = min - 0.001 (src/BIH.hs:92-95) passes a plane of the root box that no
-// ancestor has clipped yet.  Used by the incremental slab test (trav_descend).
-constexpr uint32_t kGrownLeft = 1u, kGrownRight = 2u;
-
 __device__ __forceinline__ BranchTail unpack_tail(v4f q2) {
-    const uint32_t l = __float_as_uint(q2.z), r = __float_as_uint(q2.w);
-    return BranchTail{ q2.x, q2.y, (int)((l >> 29) & 3u), l & ~kAxisMask, r & ~kAxisMask, (r >> 29) & 3u };
+    const uint32_t l = __float_as_uint(q2.z);
+    return BranchTail{ q2.x, q2.y, (int)((l >> 29) & 3u), l & ~kAxisMask, __float_as_uint(q2.w) };
 }
 __device__ __forceinline__ BranchData unpack_branch(v4f q0, v4f q1, v4f q2) {
     const BranchTail t = unpack_tail(q2);
@@ -324,7 +316,6 @@ __device__ __forceinline__ bool cull_test32(const CullBoxes32& c, bool left, f3 
 }
 struct GlobalNodes {            // every branch read from HBM/L2
     static constexpr bool kBoxInRegisters = false;
-    static constexpr bool kIncremental = false;
     static constexpr bool kCull = true;
     const float4* g;
     const float4* cull; bool cull_on;
@@ -352,21 +343,18 @@ struct HybridNodes {            // first n_lds branches (top of the tree) in LDS
 #define SQ_BOX_IN_REGISTERS 0
 #endif
     static constexpr bool kBoxInRegisters = SQ_BOX_IN_REGISTERS != 0;
-    // Incremental slab test (trav_descend): a ray carries (tmin, tmax) of its current branch's box, a child's values follow from
-    // ONE plane, and a branch visit reads one quad (planes, axis, children) instead of three.  `incr`: the tree allows it
-    // (every child box regular or grown, checked at upload) and the option is on.
-    static constexpr bool kIncremental = true;
     static constexpr bool kCull = true;
     const SQ_LDS v4f* l; const float4* g; uint32_t n_lds;
     const float4* cull; bool cull_on;
-    // SQ_STREAM_CULL16: the children's culling boxes as binary16 pairs (2 quads per branch, as in the resident form) instead of
-    // fp32 (4 quads): every lane of a divergent load is a tag lookup of its own in the L1, and a branch visit is 7 of them
-    // (3 branch quads + 4 box quads).  Coarser boxes cull less (planes move outwards by up to 2^-10 of their magnitude).
+    // SQ_STREAM_CULL16 (default): the children's culling boxes as binary16 pairs (2 quads per branch, as in the resident form)
+    // instead of fp32 (4 quads): a branch visit reads 5 quads instead of 7 and the table is half the size (4.2 MB instead of
+    // 8.3 MB on the 1M-triangle scene).  Coarser boxes cull a little less (planes move outwards by up to 2^-10 of their
+    // magnitude), but both stand-in scenes render faster: 27.5 -> 25.2 ms (82k triangles) and 32.7 -> 30.3 ms (1M triangles)
+    // at 64 spp, same call (profiles/r03a_stream_variants.txt).  -DSQ_STREAM_CULL16=0 builds the fp32 form.
 #ifndef SQ_STREAM_CULL16
-#define SQ_STREAM_CULL16 0
+#define SQ_STREAM_CULL16 1
 #endif
     const uint4* cull16;
-    bool incr;
 #if SQ_STREAM_CULL16
     struct CullBoxes { uint4 l, r; };
     __device__ __forceinline__ CullBoxes cull_load(uint32_t parent) const { return CullBoxes{ cull16[2 * (size_t)parent], cull16[2 * (size_t)parent + 1] }; }
@@ -389,11 +377,6 @@ struct HybridNodes {            // first n_lds branches (top of the tree) in LDS
         const float4 d = g[3 * b + 2];
         return unpack_tail(v4f{ d.x, d.y, d.z, d.w });
     }
-    __device__ __forceinline__ void box(uint32_t b, v4f& q0, v4f& q1) const {      // lo.xyz, lmax | hi.xyz, rmin
-        if (b < n_lds) { q0 = l[3 * b]; q1 = l[3 * b + 1]; return; }
-        const float4 a = g[3 * b], c = g[3 * b + 1];
-        q0 = v4f{ a.x, a.y, a.z, a.w }; q1 = v4f{ c.x, c.y, c.z, c.w };
-    }
 };
 // Resident encoding (whole scene in LDS).  A branch is 40 B: two 16-B quads and two reference words.
 //   reference word: bit 31 = leaf; leaf: bits 28..24 = triangle count (<= 31), bits 23..0 = first triangle;
@@ -403,7 +386,6 @@ constexpr uint32_t kResAxisMask = kAxisMask;
 #define SQ_RES_BOX_IN_REGISTERS 0
 #endif
 struct ResidentNodes {
-    static constexpr bool kIncremental = false;
     // Round 1 read a branch's own box with every visit ("LDS reads are cheap and VALU is what binds").  After the pooled
     // windows and the culling boxes it is the number of memory instructions that the frame time follows, so the box can
     // ride in six registers instead (a child's box is its parent's with one plane replaced, src/BIH.hs:130-141): a branch
@@ -447,15 +429,15 @@ struct ResidentNodes {
     __device__ __forceinline__ BranchTail tail(uint32_t b) const {
         if (SQ_RES_TAIL_GLOBAL) {   // one global load (10 KB table, L1) instead of three LDS reads: the LDS pipe is what binds
             const uint4 t = rtail[b];
-            return BranchTail{ __uint_as_float(t.x), __uint_as_float(t.y), (int)((t.z >> 29) & 3u), t.z & ~kResAxisMask, t.w, 0u };
+            return BranchTail{ __uint_as_float(t.x), __uint_as_float(t.y), (int)((t.z >> 29) & 3u), t.z & ~kResAxisMask, t.w };
         }
         if constexpr (kBoxInRegisters) {
             const v4f t = quads[b];
             const uint32_t l = __float_as_uint(t.z);
-            return BranchTail{ t.x, t.y, (int)((l >> 29) & 3u), l & ~kResAxisMask, __float_as_uint(t.w), 0u };
+            return BranchTail{ t.x, t.y, (int)((l >> 29) & 3u), l & ~kResAxisMask, __float_as_uint(t.w) };
         }
         const v2i r = refs[b];
-        return BranchTail{ q0(b).w, q1(b).w, (int)(((uint32_t)r.x >> 29) & 3u), (uint32_t)r.x & ~kResAxisMask, (uint32_t)r.y, 0u };
+        return BranchTail{ q0(b).w, q1(b).w, (int)(((uint32_t)r.x >> 29) & 3u), (uint32_t)r.x & ~kResAxisMask, (uint32_t)r.y };
     }
 };
 
@@ -591,9 +573,6 @@ struct Trav {
     f3 blo, bhi;        // NodeSrc::kBoxInRegisters: traversal box of the node `cur` (unused otherwise)
     bool cull;          // the ray is inside the limits of sq_cull_boxes: a node whose culling box it misses returns Nothing
     f3 nodf;            // -o * (1/d), for the culling slab test in FMA form
-    // NodeSrc::kIncremental, safe rays: tmin / tmax of intersectsBB (src/Geometry.hs:166-177) for the box of branch `cur`, valid
-    // while tvalid; otherwise the next branch step recomputes them from that branch's own box
-    float tn, tf; bool tvalid;
 };
 
 __device__ __forceinline__ void trav_begin(Trav& T, const SceneView& S, uint32_t root_ref, f3 o, f3 d) {
@@ -608,20 +587,9 @@ __device__ __forceinline__ void trav_begin(Trav& T, const SceneView& S, uint32_t
     }
     T.blo = sq::mk(S.root_lo[0], S.root_lo[1], S.root_lo[2]); T.bhi = sq::mk(S.root_hi[0], S.root_hi[1], S.root_hi[2]);
     T.mode = (T.cur & kLeafBit) ? M_LEAF : M_DESCEND;
-    T.tn = 0; T.tf = 0; T.tvalid = false;                               // the first branch step of an incremental traversal computes them from the root's box
     if (T.mode == M_DESCEND &&
         !slab(S.root_lo[0], S.root_lo[1], S.root_lo[2], S.root_hi[0], S.root_hi[1], S.root_hi[2], o, T.df))
         T.mode = M_DONE;                                                // src/BIH.hs:112 at the root
-}
-
-// tmin / tmax of the slab test of a box for a SAFE ray (finite o, d, 1/d, finite planes): the values the reference computes,
-// up to the sign of a zero (v_min / v_max against Haskell's min / max, see slab_fast), which no comparison can see.
-__device__ __forceinline__ void slab_interval(v4f q0, v4f q1, f3 o, f3 df, float& tn, float& tf) {
-    const float t1 = (q0.x - o.x) * df.x, t2 = (q1.x - o.x) * df.x;
-    const float t3 = (q0.y - o.y) * df.y, t4 = (q1.y - o.y) * df.y;
-    const float t5 = (q0.z - o.z) * df.z, t6 = (q1.z - o.z) * df.z;
-    tn = vmax3(vmin(t1, t2), vmin(t3, t4), vmin(t5, t6));
-    tf = vmin3(vmax(t1, t2), vmax(t3, t4), vmax(t5, t6));
 }
 
 // Near-child prefetch (resident form, pooled kernel; -DSQ_DESCEND_PREFETCH=bits, 0 = off): the kernel is bound by the
@@ -638,53 +606,6 @@ struct BranchPf { uint32_t idx; BranchData B; ResidentNodes::CullBoxes cb; bool 
 // One Branch equation (src/BIH.hs:111-141).  Pre: mode == M_DESCEND.
 template <typename NodeSrc, typename StackT>
 __device__ __forceinline__ void trav_descend(Trav& T, const NodeSrc& N, SQ_LDS StackT* stk, int stride, BranchPf* pf = nullptr) {
-    if constexpr (NodeSrc::kIncremental) {
-        // Incremental slab test.  The box of a child is its parent's with ONE plane replaced (src/BIH.hs:130-141), and
-        // (plane - o) * (1/d) is monotone in the plane under round-to-nearest.  For a safe ray and a REGULAR child (the new
-        // plane lies within the parent's interval on that axis) the child's interval on the split axis is contained in the
-        // parent's, so with t = (plane - o_a) * (1/d_a), the very product the reference forms:
-        //     left child  [lo_a, lmax]:  d_a > 0: tmax' = min(tmax, t)   d_a < 0: tmin' = max(tmin, t)   (the other one unchanged)
-        //     right child [rmin, hi_a]:  d_a > 0: tmin' = max(tmin, t)   d_a < 0: tmax' = min(tmax, t)
-        // are the reference's values for the child, bit for bit (max / min over the three axes with one term replaced by a
-        // tighter one).  A GROWN child (kGrownLeft / kGrownRight) has a box that contains its parent's; its parent passed
-        // `tmax > 0 && tmin < tmax`, the child's tmin is no larger and its tmax no smaller, so it passes too -- and its own
-        // values are not derivable from the parent's: the ray is marked and recomputes them from that child's own box if it
-        // descends into it.  A return into a FAR frame does the same (trav_unwind).  Trees with an inverted interval anywhere
-        // (never built by makeBIH; possible through the C-ABI) and unsafe rays take the plain path below.
-        if (N.incr && T.safe) {
-            // every load of the step is requested before the first one is waited for: the culling boxes, the tail quad, and --
-            // only for a ray that has to recompute -- the two quads of the branch's own box
-            typename NodeSrc::CullBoxes cbx;
-            const bool use_cull_i = T.cull && N.cull_on;
-            if (use_cull_i) cbx = N.cull_load(T.cur);
-            const BranchTail B = N.tail(T.cur);
-            if (!T.tvalid) {
-                v4f b0, b1; N.box(T.cur, b0, b1);
-                slab_interval(b0, b1, T.o, T.df, T.tn, T.tf);
-                T.tvalid = true;
-            }
-            const float oa = sq::axis_of(T.o, B.axis), dfa = sq::axis_of(T.df, B.axis);
-            const bool pos = sq::axis_of(T.d, B.axis) > 0;                  // leftToRight, src/BIH.hs:127
-            const float tl = (B.lmax - oa) * dfa, tr = (B.rmin - oa) * dfa;
-            const float tnL = pos ? T.tn : vmax(T.tn, tl), tfL = pos ? vmin(T.tf, tl) : T.tf;
-            const float tnR = pos ? vmax(T.tn, tr) : T.tn, tfR = pos ? T.tf : vmin(T.tf, tr);
-            const bool gL = (B.grown & kGrownLeft) != 0, gR = (B.grown & kGrownRight) != 0;
-            bool iL = gL || (tfL > 0 && tnL < tfL), iR = gR || (tfR > 0 && tnR < tfR);
-            if (use_cull_i) { iL = iL && N.cull_test(cbx, true, T.df, T.nodf); iR = iR && N.cull_test(cbx, false, T.df, T.nodf); }
-            bool went_left;
-            if (iL && iR) {
-                stk[T.sp * stride] = (StackT)T.cur; ++T.sp;                 // FAR(cur)
-                went_left = pos;
-            } else if (iL) went_left = true;
-            else if (iR) went_left = false;
-            else { T.R.tri = -1; T.mode = M_UNWIND; return; }               // src/BIH.hs:119
-            T.cur = went_left ? B.left : B.right;
-            T.tn = went_left ? tnL : tnR; T.tf = went_left ? tfL : tfR;
-            T.tvalid = !(went_left ? gL : gR);
-            if (T.cur & kLeafBit) T.mode = M_LEAF;
-            return;
-        }
-    }
     v4f q0, q1; int ax; uint32_t left, right;
     constexpr bool kPf = (SQ_DESCEND_PREFETCH != 0) && std::is_same<NodeSrc, ResidentNodes>::value;
     bool have = false;
@@ -839,7 +760,7 @@ __device__ __forceinline__ void trav_unwind(Trav& T, const NodeSrc& N, const Tri
     if constexpr (NodeSrc::kBoxInRegisters) {
         const BranchData D = N.load(e);                                 // this branch's own box again; the far child's follows below
         T.blo = sq::mk(D.q0.x, D.q0.y, D.q0.z); T.bhi = sq::mk(D.q1.x, D.q1.y, D.q1.z);
-        B = BranchTail{ D.q0.w, D.q1.w, D.axis, D.left, D.right, 0u };
+        B = BranchTail{ D.q0.w, D.q1.w, D.axis, D.left, D.right };
     } else B = N.tail(e);
     const int ax = B.axis;
     const bool l2r = sq::axis_of(T.d, ax) > 0;
@@ -851,7 +772,6 @@ __device__ __forceinline__ void trav_unwind(Trav& T, const NodeSrc& N, const Tri
         T.csp = T.sp; T.ct = T.R.t; ++T.sp;
     }
     T.cur = l2r ? B.right : B.left;                                     // the far child
-    T.tvalid = false;                                                   // incremental slab: its (tmin, tmax) come from its own box
     if constexpr (NodeSrc::kBoxInRegisters) {
         if (l2r) { if (ax == 0) T.blo.x = B.rmin; else if (ax == 1) T.blo.y = B.rmin; else T.blo.z = B.rmin; }
         else     { if (ax == 0) T.bhi.x = B.lmax; else if (ax == 1) T.bhi.y = B.lmax; else T.bhi.z = B.lmax; }
