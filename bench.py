@@ -10,7 +10,7 @@ under torchrun (WORLD_SIZE set) it IS one of the ranks.  It exits non-zero if fe
 A step is one pass of the hot path over one frame: every pixel's `samples` paths are traced, accumulated in
 sample order and tonemapped (src/Lib.hs:68-137).  The scene is already resident in HBM when the timed region
 starts.  With N ranks the SAME frame (strong scaling, the default: 1080p @ 256 spp in total) is cut into
-interleaved blocks of 8 rows, each rank renders its rows on its GPU, and one RCCL all_gather_into_tensor
+interleaved blocks of 2 rows, each rank renders its rows on its GPU, and one RCCL all_gather_into_tensor
 reassembles the RGB8 framebuffer inside the timed region.  `--scaling weak` renders the frame at 256*N spp instead
 (per-GPU work fixed).  `--config c4` is BASELINE.json configs[3]: 3840x2160 @ 1024 spp.
 """

@@ -51,7 +51,7 @@ typedef struct {
 
 /* ---- one-shot drop-in for src/Lib.hs:73-74 ---- */
 /* The reference host is one process, so the one-shot calls put a node's GPUs to work themselves: rows are cut
- * into interleaved blocks of 8 (the sq_shard scheme below), one host thread per device renders its shard, and
+ * into interleaved blocks of 2 rows (the sq_shard scheme below), one host thread per device renders its shard, and
  * the shards are de-interleaved into `out`; no exchange between devices is needed (a pixel depends only on
  * x, y, samples, w).  Devices: all visible ones when the frame has >= 2^24 samples, else device 0; the
  * environment variable SQ_DEVICES="0,1,3" names them explicitly (an index may repeat).

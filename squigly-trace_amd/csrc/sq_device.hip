@@ -50,7 +50,7 @@ constexpr int kTraceBlock = 512;   // persistent trace kernel, streaming form: 8
 #define SQ_RESIDENT_BLOCK 1024       // diagnostic builds: 768 / 512 = three / two waves per SIMD (how the frame time follows occupancy)
 #endif
 constexpr int kResidentBlock = SQ_RESIDENT_BLOCK; // persistent trace kernel, resident form: one workgroup per CU owns the whole scene in LDS
-constexpr int kOneshotRowBlock = 8; // rows per block when a one-shot call shards a frame over devices
+constexpr int kOneshotRowBlock = 2; // rows per block when a one-shot call shards a frame over devices (balance: squigly-trace_amd/dist.py)
 // Slots a wave reserves from the queue per atomic (multiple of 256 for the resident form).  Every reservation stalls
 // the wave for the atomic's round trip and then for the flag loads of the scan, and a sparse chunk (8 % of the slots
 // are live at the second bounce level) serves only part of the idle lanes: 64 -> 128 -> 256 -> 512 slots measured
@@ -444,13 +444,27 @@ __global__ void __launch_bounds__(kBlock) sq_accumulate(const SceneView S, const
     for (int a = blockIdx.x * kBlock + threadIdx.x; a < A; a += gridDim.x * kBlock) {
         f3 sum = sq::mk(W.px_sum[3 * a], W.px_sum[3 * a + 1], W.px_sum[3 * a + 2]);
         const Surface s0 = surface_of(S, W.px_tri0[a]);
-        uint8_t st = k_count > 0 ? W.state[a] : kDone;                 // the next slot's state is requested one sample ahead
-        for (int k = 0; k < k_count; ++k) {
-            const long long sid = (long long)k * A + a;
-            const uint8_t cur = st;
-            if (k + 1 < k_count) st = W.state[sid + A];
-            const f3 rad = (cur == kRay2) ? shade2_radiance(S, W, sid, s0) : sq::mk(W.rad[3 * sid], W.rad[3 * sid + 1], W.rad[3 * sid + 2]);
-            sum = sum + rad;
+        // The sum is the reference's left fold over the samples (src/Lib.hs:88), one dependent add per sample -- but the loads
+        // need not be one round trip per sample: the states and radiances of kAccGroup samples are requested together (a slot
+        // that still holds a second bounce ray has no radiance yet; what is read there is not used) and then added in order.
+        // On one rank's share of a frame at 8 ranks, where a thread was a chain of 256 such round trips: 384 -> 295 us with groups of 8.
+        constexpr int kAccGroup = 16;
+        for (int k0 = 0; k0 < k_count; k0 += kAccGroup) {
+            uint8_t st[kAccGroup]; float rx[kAccGroup], ry[kAccGroup], rz[kAccGroup];
+#pragma unroll
+            for (int j = 0; j < kAccGroup; ++j) {
+                const int k = min(k0 + j, k_count - 1);                 // past the end: the last sample again, dropped below
+                const long long sid = (long long)k * A + a;
+                st[j] = W.state[sid];
+                rx[j] = W.rad[3 * sid]; ry[j] = W.rad[3 * sid + 1]; rz[j] = W.rad[3 * sid + 2];
+            }
+#pragma unroll
+            for (int j = 0; j < kAccGroup; ++j) {
+                if (k0 + j >= k_count) break;
+                const long long sid = (long long)(k0 + j) * A + a;
+                const f3 rad = (st[j] == kRay2) ? shade2_radiance(S, W, sid, s0) : sq::mk(rx[j], ry[j], rz[j]);
+                sum = sum + rad;
+            }
         }
         if (!last) { W.px_sum[3 * a] = sum.x; W.px_sum[3 * a + 1] = sum.y; W.px_sum[3 * a + 2] = sum.z; continue; }
         const f3 avg = sq::scale(1 / (float)F.samples, sum);
@@ -1903,7 +1917,7 @@ int oneshot_devices(int64_t total_samples, int32_t w, std::vector<int>& out) {
 }
 
 // The foreign call of src/Lib.hs:73-74.  The reference host is ONE process, so this is where a node's GPUs are
-// put to work for it: rows are cut into interleaved blocks of 8 (the sq_shard scheme), one host thread per
+// put to work for it: rows are cut into interleaved blocks of 2 (the sq_shard scheme), one host thread per
 // device renders its shard, and the shards are de-interleaved into the caller's image.  No exchange between
 // devices: a pixel depends only on (x, y, samples, w).
 int render_oneshot(const sq_scene* scene, const sq_camera* cam, int32_t samples, int32_t w, int32_t h, int32_t cast,

@@ -8,7 +8,10 @@ This plays the role of massiv's `Par` scheduler (src/Lib.hs:73) one level up.
 import torch
 import torch.distributed as dist
 
-ROW_BLOCK = 8   # rows per block: small enough to balance the very non-uniform image, large enough for whole tiles
+# Rows per block of the interleaved partition.  Measured on the headline frame at 8 ranks (tools/gpu_share_balance.py, every shard timed
+# alone on one MI355X, profiles/r03i_share_balance.txt): slowest shard 8.62 / 8.56 / 8.67 / 8.83 / 9.00 / 10.39 ms with blocks of
+# 1 / 2 / 4 / 8 / 16 / 32 rows (mean 8.5 ms throughout) -- the frame time of a strong-scaling run is the slowest rank's.
+ROW_BLOCK = 2
 
 
 def shard_rows(w, row_block, rank, world):

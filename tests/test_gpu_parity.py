@@ -360,7 +360,7 @@ def test_cpp_cli_writes_the_golden_image(sqt, tmp_path):
 
 def test_config_c4_shard_of_eight(sqt, product_scene, oracle_scene, dev):
     """BASELINE configs[3]: 3840x2160 @ 1024 spp tiled over 8 GPUs.  One rank's shard (rank 3 of 8, interleaved
-    blocks of 8 rows) is rendered on this GPU; two of its rows are compared with the oracle bit for bit.
+    blocks of d.ROW_BLOCK rows) is rendered on this GPU; two of its rows are compared with the oracle bit for bit.
     Seeds reach 1024*(2159 + 3839*3840) = 1.5e10 > 2^32 here."""
     import torch
     from importlib import import_module
@@ -429,7 +429,7 @@ def test_randomised_campaign(sqt, O):
 def test_one_shot_call_spreads_over_devices(sqt, product_scene, oracle_scene, monkeypatch):
     """sq_render_rgb8 / sq_render_f32 shard the rows over SQ_DEVICES (default: every visible GPU for large frames),
     one host thread per device, and de-interleave the result.  On a one-GPU box the same device is named several
-    times: the threading, the 8-row interleave and the ragged last block are what is under test."""
+    times: the threading, the 2-row interleave and the ragged last block are what is under test."""
     bih, cam, _ = product_scene
     ob, ocam, _ = oracle_scene
     want = np.load(os.path.join(GOLDEN, "scene_64x64_4spp_avg.npy"))
@@ -438,7 +438,7 @@ def test_one_shot_call_spreads_over_devices(sqt, product_scene, oracle_scene, mo
         assert np.array_equal(bits(sqt.render_f32(bih, cam, 4, (64, 64))), bits(want)), devs
         assert np.array_equal(sqt.render_rgb8(bih, cam, 4, (64, 64)), np.load(os.path.join(GOLDEN, "scene_64x64_4spp_rgb8.npy"))), devs
     monkeypatch.setenv("SQ_DEVICES", "0,0,0")
-    o, o8, _ = ob.render(ocam, 5, 37, 29, threads=THREADS)                # 37 rows: blocks of 8,8,8,8,5
+    o, o8, _ = ob.render(ocam, 5, 37, 29, threads=THREADS)                # 37 rows: 18 blocks of 2 and a last one of 1
     assert np.array_equal(bits(sqt.render_f32(bih, cam, 5, (37, 29))), bits(o))
     assert np.array_equal(sqt.render_rgb8(bih, cam, 5, (37, 29)), o8)
     oc, _, _ = ob.render(ocam, 1, 37, 29, cast=True, threads=THREADS)
