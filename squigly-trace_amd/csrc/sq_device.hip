@@ -444,25 +444,38 @@ __global__ void __launch_bounds__(kBlock) sq_accumulate(const SceneView S, const
     for (int a = blockIdx.x * kBlock + threadIdx.x; a < A; a += gridDim.x * kBlock) {
         f3 sum = sq::mk(W.px_sum[3 * a], W.px_sum[3 * a + 1], W.px_sum[3 * a + 2]);
         const Surface s0 = surface_of(S, W.px_tri0[a]);
-        // The sum is the reference's left fold over the samples (src/Lib.hs:88), one dependent add per sample -- but the loads
-        // need not be one round trip per sample: the states and radiances of kAccGroup samples are requested together (a slot
-        // that still holds a second bounce ray has no radiance yet; what is read there is not used) and then added in order.
-        // On one rank's share of a frame at 8 ranks, where a thread was a chain of 256 such round trips: 384 -> 295 us with groups of 8.
-        constexpr int kAccGroup = 16;
-        for (int k0 = 0; k0 < k_count; k0 += kAccGroup) {
-            uint8_t st[kAccGroup]; float rx[kAccGroup], ry[kAccGroup], rz[kAccGroup];
+        // The sum is the reference's left fold over the samples (src/Lib.hs:88): one dependent add per sample.  With fewer active
+        // pixels than threads (one rank's share of a frame at 8 ranks) a thread is a chain of `samples` memory round trips and the
+        // launch lasts as long as that chain: there the states and radiances of 16 samples are requested together (a slot that
+        // still holds a second bounce ray has no radiance yet; what is read there is not used) and then added in order -- 384 ->
+        // 280 us on such a share.  A whole frame is bound by the bytes it moves and keeps the one-sample-ahead loop (0.83 ms;
+        // the grouped loop takes 0.98 ... 1.58 ms there with groups of 2 ... 16: profiles/r03l_accumulate_groups.txt).
+        if ((long long)A * 2 <= (long long)gridDim.x * kBlock) {
+            constexpr int kAccGroup = 16;
+            for (int k0 = 0; k0 < k_count; k0 += kAccGroup) {
+                uint8_t st[kAccGroup]; float rx[kAccGroup], ry[kAccGroup], rz[kAccGroup];
 #pragma unroll
-            for (int j = 0; j < kAccGroup; ++j) {
-                const int k = min(k0 + j, k_count - 1);                 // past the end: the last sample again, dropped below
-                const long long sid = (long long)k * A + a;
-                st[j] = W.state[sid];
-                rx[j] = W.rad[3 * sid]; ry[j] = W.rad[3 * sid + 1]; rz[j] = W.rad[3 * sid + 2];
+                for (int j = 0; j < kAccGroup; ++j) {
+                    const int k = min(k0 + j, k_count - 1);             // past the end: the last sample again, dropped below
+                    const long long sid = (long long)k * A + a;
+                    st[j] = W.state[sid];
+                    rx[j] = W.rad[3 * sid]; ry[j] = W.rad[3 * sid + 1]; rz[j] = W.rad[3 * sid + 2];
+                }
+#pragma unroll
+                for (int j = 0; j < kAccGroup; ++j) {
+                    if (k0 + j >= k_count) break;
+                    const long long sid = (long long)(k0 + j) * A + a;
+                    const f3 rad = (st[j] == kRay2) ? shade2_radiance(S, W, sid, s0) : sq::mk(rx[j], ry[j], rz[j]);
+                    sum = sum + rad;
+                }
             }
-#pragma unroll
-            for (int j = 0; j < kAccGroup; ++j) {
-                if (k0 + j >= k_count) break;
-                const long long sid = (long long)(k0 + j) * A + a;
-                const f3 rad = (st[j] == kRay2) ? shade2_radiance(S, W, sid, s0) : sq::mk(rx[j], ry[j], rz[j]);
+        } else {
+            uint8_t st = k_count > 0 ? W.state[a] : kDone;             // the next slot's state is requested one sample ahead
+            for (int k = 0; k < k_count; ++k) {
+                const long long sid = (long long)k * A + a;
+                const uint8_t cur = st;
+                if (k + 1 < k_count) st = W.state[sid + A];
+                const f3 rad = (cur == kRay2) ? shade2_radiance(S, W, sid, s0) : sq::mk(W.rad[3 * sid], W.rad[3 * sid + 1], W.rad[3 * sid + 2]);
                 sum = sum + rad;
             }
         }

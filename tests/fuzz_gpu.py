@@ -242,6 +242,11 @@ def run_case(seed, kinds=12):
              # from the seed, not from rng: the draws that follow stay what they were for every recorded seed.  Campaign seeds only
              # (>= 2e6): the slice in `pytest -m gpu` (seeds 1000..1399, 504773) keeps the knobs it has always had
              "primary_pooled": int(seed >= 2000000 and ((seed * 2654435761) >> 7) % 4 == 0)}
+    if seed >= 30000000:   # round-3 campaign seeds: the streaming form's plain (1, 2 workgroups per CU) and six-wave (0 = auto, 3) builds
+        knobs["trace_blocks_per_cu"] = ((seed * 40503) >> 3) % 4
+        if BIG:            # the overlapped schedules' scheduling options (BIG draws `overlap` below)
+            knobs["aux_polite"] = ((seed * 2246822519) >> 5) % 3
+            knobs["trace_prio"] = (((seed * 3266489917) >> 4) % 2) * 2
     for kv in os.environ.get("SQ_FUZZ_FORCE", "").split(","):          # e.g. SQ_FUZZ_FORCE=primary_pooled=1,cull=0
         if "=" in kv:
             knobs[kv.split("=")[0]] = int(kv.split("=")[1])
