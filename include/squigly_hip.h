@@ -66,7 +66,7 @@ int sq_render_rgb8(const sq_scene* scene, const sq_camera* cam, int32_t samples,
 int sq_render_f32(const sq_scene* scene, const sq_camera* cam, int32_t samples, int32_t w, int32_t h,
                   int32_t cast, float* out_avg);
 
-/* Frame workspaces (up to 32 GB for a 1080p frame at 256 spp) are kept, one block per device, when a scene is
+/* Frame workspaces (15 GB for a 1080p frame at 256 spp, at most 24 GB) are kept, one block per device, when a scene is
  * freed, so that repeated one-shot calls do not re-allocate them (a hipMalloc right after the hipFree of a block
  * that large can wait seconds for the driver to scrub it).  This hands them back to the driver. */
 void sq_release_cached_memory(void);
@@ -115,7 +115,11 @@ int  sq_get_stats(sq_device_scene* s, uint64_t* out, int32_t n, int32_t reset);
  *   "primary_pooled"     1 = the primary rays go through the pooled trace kernel (one slot per pixel, one launch) instead of the
  *                        one-ray-per-lane pass: one rank's share of the headline frame at 8 ranks 8.20 -> 8.12 ms, the whole
  *                        frame 54.2 -> 54.4 ms; default 0
- *   "guided"             1 = queue reservations shrink towards the end of a launch (default), 0 = fixed size
+ *   "guided"             bit 0 (default 1): queue reservations of the first-bounce launches shrink towards the end of the queue, so that a
+ *                        launch does not end with a few waves still working through a full reservation; bit 1: the same for the
+ *                        second-bounce launches -- off by default since round 3: their queue is 8 % live, a shrunken reservation brings
+ *                        a handful of rays for the same atomic and scan round trip, and every such launch took 0.34 ms longer with it
+ *                        (one rank's share at 8 ranks: 1166 -> 825 us; whole frame: 4886 -> 4542 us); 0 = fixed size everywhere
  *   "straggler_lanes"    pool = 0: lanes still traversing when a wave turns to its leaves (default 8)
  *   "trace_blocks_per_cu" streaming form: 512-thread workgroups per CU.  0 (default) = three, with the kernel compiled for six waves per
  *                        SIMD (80 VGPRs), when a workgroup's stacks plus at least 4 KB of the tree's top fit in a third of the LDS, else

@@ -503,7 +503,8 @@ struct TraceArgs {
     int32_t n_lds; int32_t stack_cap; int32_t straggler_lanes;
     int32_t chunk;               // slots per reservation: a multiple of 64, at most kChunkResident / kChunkStreaming
     int32_t guide_shift;         // towards the end of the queue a reservation shrinks to (slots left >> guide_shift), so that the
-                                 //   launch does not end with a few waves still working through a full reservation
+                                 //   launch does not end with a few waves still working through a full reservation (first bounce level
+                                 //   only by default: on the sparse second-level queue it costs more round trips than it saves, option "guided")
     int32_t refill_min;          // pooled form: idle lanes a wave collects before it fetches new rays for them
     int32_t flush_min;           // pooled form: a trailing part-filled window of the pair pool is run at once from this many pairs on
     int32_t descend_extra, descend_lanes;   // pooled form: further branch steps per iteration for lanes that keep descending, and how many such lanes it takes
@@ -1610,7 +1611,7 @@ int launch_frame(sq_device_scene* s, const Frame& F, hipStream_t stream) {
         const bool pixel_major = s->opt_pixel_major < 0 ? (!resident && (size_t)S.n_tris * sizeof(DevTri) > ((size_t)4 << 20)) : s->opt_pixel_major != 0;
         int guide_shift = 2;                                            // log2(4 x waves of the launch), rounded up
         while ((1ll << guide_shift) < 4ll * trace_blocks * (trace_threads / 64)) ++guide_shift;
-        if (!s->opt_guided) guide_shift = 62;
+        if (!((s->opt_guided >> level) & 1)) guide_shift = 62;         // bit 0: first bounce level (and the mirror / primary launches), bit 1: second
         TraceArgs A{ W.org, W.dir, W.state, level == 0 ? (int32_t)kRay1 : (int32_t)kRay2, (long long)s->work.slot_capacity, with_mirror_rays ? 1 : 0,
                      W.n_active, kc, W.head[level], n_lds, stack_cap, (int32_t)s->opt_straggler, chunk, guide_shift,
                      (int32_t)s->opt_refill_min, (int32_t)s->opt_flush_min, (int32_t)s->opt_descend_extra, (int32_t)s->opt_descend_lanes,
@@ -1831,7 +1832,7 @@ extern "C" int sq_set_option(sq_device_scene* s, const char* key, int64_t value)
     if (!std::strcmp(key, "trace_blocks_per_cu")) { if (value < 0 || value > 8) return sq_set_error("trace_blocks_per_cu must be in 0..8"); s->opt_trace_blocks_per_cu = value; return 0; }
     if (!std::strcmp(key, "overlap")) { if (value < 0 || value > 2) return sq_set_error("overlap must be 0, 1 or 2"); s->opt_overlap = value; return 0; }
     if (!std::strcmp(key, "pool")) { s->opt_pool = value ? 1 : 0; return 0; }
-    if (!std::strcmp(key, "guided")) { s->opt_guided = value ? 1 : 0; return 0; }
+    if (!std::strcmp(key, "guided")) { if (value < 0 || value > 3) return sq_set_error("guided must be in 0..3"); s->opt_guided = value; return 0; }
     if (!std::strcmp(key, "primary_resident")) { s->opt_primary_resident = value ? 1 : 0; return 0; }
     if (!std::strcmp(key, "cull")) { s->opt_cull = value ? 1 : 0; return 0; }
     if (!std::strcmp(key, "primary_pooled")) { s->opt_primary_pooled = value != 0; return 0; }

@@ -244,6 +244,7 @@ def run_case(seed, kinds=12):
              "primary_pooled": int(seed >= 2000000 and ((seed * 2654435761) >> 7) % 4 == 0)}
     if seed >= 30000000:   # round-3 campaign seeds: the streaming form's plain (1, 2 workgroups per CU) and six-wave (0 = auto, 3) builds
         knobs["trace_blocks_per_cu"] = ((seed * 40503) >> 3) % 4
+        knobs["guided"] = ((seed * 2654435761) >> 11) % 4          # per bounce level since round 3
         if BIG:            # the overlapped schedules' scheduling options (BIG draws `overlap` below)
             knobs["aux_polite"] = ((seed * 2246822519) >> 5) % 3
             knobs["trace_prio"] = (((seed * 3266489917) >> 4) % 2) * 2
