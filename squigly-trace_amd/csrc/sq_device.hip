@@ -439,6 +439,8 @@ __device__ __forceinline__ f3 shade2_radiance(const SceneView& S, const Work& W,
 }
 
 // sum outcomes, in sample order (src/Lib.hs:88); on the last batch: avg, tonemap, store.
+// GROUPED: see the comment in the loop; two kernels because the grouped loop's registers cost the plain one a third of its waves.
+template <bool GROUPED>
 __global__ void __launch_bounds__(kBlock) sq_accumulate(const SceneView S, const Frame F, const Work W, int k_count, int last) {
     const int A = *W.n_active;
     for (int a = blockIdx.x * kBlock + threadIdx.x; a < A; a += gridDim.x * kBlock) {
@@ -446,11 +448,11 @@ __global__ void __launch_bounds__(kBlock) sq_accumulate(const SceneView S, const
         const Surface s0 = surface_of(S, W.px_tri0[a]);
         // The sum is the reference's left fold over the samples (src/Lib.hs:88): one dependent add per sample.  With fewer active
         // pixels than threads (one rank's share of a frame at 8 ranks) a thread is a chain of `samples` memory round trips and the
-        // launch lasts as long as that chain: there the states and radiances of 16 samples are requested together (a slot that
+        // launch lasts as long as that chain: there (GROUPED, chosen by the host from the shard's pixel count) the states and radiances of 16 samples are requested together (a slot that
         // still holds a second bounce ray has no radiance yet; what is read there is not used) and then added in order -- 384 ->
         // 280 us on such a share.  A whole frame is bound by the bytes it moves and keeps the one-sample-ahead loop (0.83 ms;
         // the grouped loop takes 0.98 ... 1.58 ms there with groups of 2 ... 16: profiles/r03l_accumulate_groups.txt).
-        if ((long long)A * 2 <= (long long)gridDim.x * kBlock) {
+        if constexpr (GROUPED) {
             constexpr int kAccGroup = 16;
             for (int k0 = 0; k0 < k_count; k0 += kAccGroup) {
                 uint8_t st[kAccGroup]; float rx[kAccGroup], ry[kAccGroup], rz[kAccGroup];
@@ -1589,6 +1591,9 @@ int launch_frame(sq_device_scene* s, const Frame& F, hipStream_t stream) {
     }
     SQ_HIP(hipGetLastError());
     const int aux_blocks = s->n_cu * (int)(s->opt_aux_blocks_per_cu ? s->opt_aux_blocks_per_cu : 8);
+    // sq_accumulate: the grouped loop when the shard has no more pixels than the launch has threads (every thread at most one pixel)
+    const bool acc_grouped = pixels <= (long long)aux_blocks * kBlock;
+#define SQ_LAUNCH_ACCUMULATE(...) do { if (acc_grouped) hipLaunchKernelGGL(sq_accumulate<true>, __VA_ARGS__); else hipLaunchKernelGGL(sq_accumulate<false>, __VA_ARGS__); } while (0)
     // per-sample kernels that run one thread per active pixel: x covers the pixels, y splits a pixel's samples when the
     // frame has too few pixels to fill the chip (one rank's share of a frame, small frames)
     auto pp_grid = [&](int kc) {
@@ -1660,7 +1665,7 @@ int launch_frame(sq_device_scene* s, const Frame& F, hipStream_t stream) {
                 if (level == 0) hipLaunchKernelGGL(sq_shade1, pp_grid(kc), dim3(kBlock), 0, stream, S, F, W, kc);
                 SQ_HIP(hipGetLastError());
             }
-            hipLaunchKernelGGL(sq_accumulate, dim3(aux_blocks), dim3(kBlock), 0, stream, S, F, W, kc, (k0 + kc >= F.samples) ? 1 : 0);
+            SQ_LAUNCH_ACCUMULATE( dim3(aux_blocks), dim3(kBlock), 0, stream, S, F, W, kc, (k0 + kc >= F.samples) ? 1 : 0);
             SQ_HIP(hipGetLastError());
         }
         return 0;
@@ -1706,7 +1711,7 @@ int launch_frame(sq_device_scene* s, const Frame& F, hipStream_t stream) {
             SQ_HIP(hipGetLastError());
             if (launch_trace(V, kc, 1, on)) return 1;
             if (i > 0) SQ_HIP(hipStreamWaitEvent(on, eAcc[(size_t)i - 1], 0));
-            hipLaunchKernelGGL(sq_accumulate, dim3(aux_blocks), dim3(kBlock), 0, on, S, F, V, kc, i == n_real - 1 ? 1 : 0);
+            SQ_LAUNCH_ACCUMULATE( dim3(aux_blocks), dim3(kBlock), 0, on, S, F, V, kc, i == n_real - 1 ? 1 : 0);
             SQ_HIP(hipGetLastError());
             SQ_HIP(hipEventRecord(eAcc[(size_t)i], on));
         }
@@ -1744,7 +1749,7 @@ int launch_frame(sq_device_scene* s, const Frame& F, hipStream_t stream) {
     };
     auto finish = [&](int i) -> int {                       // on X, in batch order: the per-pixel sum is ordered (src/Lib.hs:88)
         SQ_HIP(hipStreamWaitEvent(X, eT2[(size_t)i], 0));
-        hipLaunchKernelGGL(sq_accumulate, dim3(aux_blocks), dim3(kBlock), 0, X, S, F, Wt[i & 1], kc_of(i), i == n_real - 1 ? 1 : 0);
+        SQ_LAUNCH_ACCUMULATE( dim3(aux_blocks), dim3(kBlock), 0, X, S, F, Wt[i & 1], kc_of(i), i == n_real - 1 ? 1 : 0);
         SQ_HIP(hipGetLastError());
         if (i + 2 < n_real) return gen(i + 2);              // the track is free again
         return 0;
