@@ -141,7 +141,9 @@ int  sq_get_stats(sq_device_scene* s, uint64_t* out, int32_t n, int32_t reset);
  *   "descend_lanes"      each taken only while at least this many lanes (default 16) of the wave want one
  *   "cull"               1 (default): a ray inside the limits of sq_cull_boxes (squigly_host.h) that misses a leaf's culling box
  *                        skips the leaf's triangle tests -- the reference's mollerTrumbore would reject them all, so no bit
- *                        changes; 0: every leaf the reference visits is tested */
+ *                        changes; 0: every leaf the reference visits is tested
+ *   "incremental"        only in builds with -DSQ_RES_INCREMENTAL=1 (measured and rejected): the resident form carries
+ *                        (tmin, tmax) of the reference's slab test down the tree instead of testing both children from scratch */
 int  sq_set_option(sq_device_scene* s, const char* key, int64_t value);
 
 /* Diagnostics for the numeric spec (tests only): evaluate one primitive on the device for n inputs.

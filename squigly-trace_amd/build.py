@@ -88,5 +88,6 @@ def build(force=False, extra=(), out=None):
 
 if __name__ == "__main__":
     outs = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--out=")]
-    print(build(force="--force" in sys.argv, extra=[a for a in sys.argv[1:] if a[:2] in ("-R", "-D") or a.startswith("-save")],
+    # -Dname[=v] / -Rpass / -save-temps go to hipcc as they are; --flag=<anything> passes <anything> (e.g. --flag=-mllvm --flag=-amdgpu-skip-threshold=24)
+    print(build(force="--force" in sys.argv, extra=[a for a in sys.argv[1:] if a[:2] in ("-R", "-D") or a.startswith("-save")] + [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--flag=")],
                 out=os.path.join(HERE, outs[0]) if outs else None))

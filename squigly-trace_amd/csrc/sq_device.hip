@@ -204,7 +204,7 @@ __device__ __forceinline__ void diag_aux_wave(const Work& W, int diag, bool at_s
 
 // Appends `want` lanes of this wave to a list with one atomic: wave ballot + prefix rank.
 __device__ __forceinline__ int wave_append(int32_t* counter, bool want) {
-    const unsigned long long m = __ballot(want);
+    const unsigned long long m = sq_ballot(want);
     if (m == 0) return -1;
     const int lane = threadIdx.x & 63;
     const int leader = __ffsll((long long)m) - 1;
@@ -551,8 +551,8 @@ __device__ __forceinline__ void stage_resident_scene(const SceneView& S, int n_b
     SQ_LDS v2i* lrefs = to_lds<v2i>(lds + L.refs);
     SQ_LDS v4f* lv = to_lds<v4f>(lds + L.verts);
     SQ_LDS v4us* lt = to_lds<v4us>(lds + L.trix);
-    SQ_LDS v2f* lboxes = to_lds<v2f>(lds + L.quads + 16u * (uint32_t)n_branches);   // kBoxInRegisters: 24-byte boxes behind the 16-byte tails
-    if constexpr (ResidentNodes::kBoxInRegisters) {
+    SQ_LDS v2f* lboxes = to_lds<v2f>(lds + L.quads + 16u * (uint32_t)n_branches);   // kTailLayout: 24-byte boxes behind the 16-byte tails
+    if constexpr (ResidentNodes::kTailLayout) {
         for (int i = threadIdx.x; i < n_branches; i += BLOCK) {
             const uint32_t* r = S.rbranch + 10 * (size_t)i;
             lquads[i] = v4f{ __uint_as_float(r[3]), __uint_as_float(r[7]), __uint_as_float(r[8]), __uint_as_float(r[9]) };
@@ -592,7 +592,7 @@ __device__ __forceinline__ void stage_resident_scene(const SceneView& S, int n_b
     }
 #endif
     if (threadIdx.x < ResidentTris::kRunPad) lt[S.n_tris + threadIdx.x] = v4us{ 0, 0, 0, 0 };
-    N = ResidentNodes{ lquads, lquads + n_branches, lrefs, lboxes, S.cull_child16 != nullptr, S.cull_child16, S.rtail };
+    N = ResidentNodes{ lquads, lquads + n_branches, lrefs, lboxes, S.cull_child16 != nullptr, S.cull_child16, S.rtail, S.incremental_ok != 0 };
     G = ResidentTris{ lt };
     if ((uintptr_t)lv != 0) __builtin_trap();                              // the kernels that use this have no static LDS: dynamic LDS starts at address 0
 }
@@ -644,7 +644,11 @@ __device__ __forceinline__ void trace_rays_body(const SceneView& S, const TraceA
         root_ref = S.rroot;
     } else {
         for (int i = threadIdx.x; i < 3 * A.n_lds; i += BLOCK) { const float4 q = S.branches[i]; lquads[i] = v4f{ q.x, q.y, q.z, q.w }; }
-        N = HybridNodes{ lquads, S.branches, (uint32_t)A.n_lds, S.cull_child, S.cull_child != nullptr, S.cull_child16 };
+#if SQ_STREAM_CULL16
+        N = HybridNodes{ lquads, HybridNodes::kMerged ? S.branches_m : S.branches, (uint32_t)A.n_lds, S.cull_child != nullptr, S.cull_child16 };
+#else
+        N = HybridNodes{ lquads, S.branches, (uint32_t)A.n_lds, S.cull_child != nullptr, S.cull_child };
+#endif
         G = GlobalTris{ S.tris, S.leaves, S.packed_leaves != 0, (size_t)S.n_tris * sizeof(DevTri) > ((size_t)4 << 20) };
         root_ref = S.root_ref;
     }
@@ -692,7 +696,7 @@ __device__ __forceinline__ void trace_rays_body(const SceneView& S, const TraceA
                 if (j * 64 >= this_chunk) break;
                 const long long idx = chunk_base + j * 64 + lane;
                 const bool alive = idx < n && A.state[slot_of(idx)] == (uint8_t)A.want;
-                const unsigned long long am = __ballot(alive);
+                const unsigned long long am = sq_ballot(alive);
                 if (alive) live[list_len + __popcll(am & lt_mask)] = (LiveT)((j & 3) * 64 + lane);   // index within its 256-slot block
                 list_len += __popcll(am);
                 if ((j & 3) == 3 && j / 4 < 3) sub_end[j / 4] = list_len;
@@ -744,7 +748,7 @@ __device__ __forceinline__ void trace_rays_body(const SceneView& S, const TraceA
             if (PROFILE) ++pf_adv;
             const bool idle = (T.mode == M_DONE);
             if (idle && my_ray >= 0) { *reinterpret_cast<int2*>(A.org + my_ray) = make_int2(__float_as_int(T.R.t), T.R.tri); my_ray = -1; }
-            const unsigned long long m = __ballot(idle);
+            const unsigned long long m = sq_ballot(idle);
             if (m) {
                 if (__popcll(m) >= A.refill_min || m == ~0ull) refill(m, idle);
                 if (exhausted && m == ~0ull) break;
@@ -770,7 +774,7 @@ __device__ __forceinline__ void trace_rays_body(const SceneView& S, const TraceA
             // to `descend_extra` more steps in this iteration (while at least `descend_lanes` of them are), instead of paying a
             // whole iteration -- return step, leaf scan, windows -- per branch step.
             for (int x = 0; x < A.descend_extra; ++x) {
-                if (__popcll(__ballot(T.mode == M_DESCEND)) < A.descend_lanes) break;
+                if (__popcll(sq_ballot(T.mode == M_DESCEND)) < A.descend_lanes) break;
                 if (PROFILE) pl_desc += (T.mode == M_DESCEND);
                 if (T.mode == M_DESCEND) trav_descend(T, N, stk, BLOCK, &pf);
             }
@@ -790,7 +794,7 @@ __device__ __forceinline__ void trace_rays_body(const SceneView& S, const TraceA
                 // lookup's integer VALU work comes next.
                 constexpr int NT = RESIDENT ? kPoolTrisResident : kPoolTrisStreaming;
                 const int c2 = (T.mode == M_LEAFQ) ? lf_cnt : 0;                // triangles left in this lane's open leaf
-                if (__ballot(c2 > 0) == 0) continue;
+                if (sq_ballot(c2 > 0) == 0) continue;
                 const int u = (c2 + NT - 1) / NT;                               // units
                 const int incl = wave_scan_add(u);
                 const int U = __builtin_amdgcn_readlane(incl, 63);
@@ -799,7 +803,7 @@ __device__ __forceinline__ void trace_rays_body(const SceneView& S, const TraceA
                 const int tri_end = lf_first + c2;                              // one past the leaf's last triangle
                 int nwin = U >> 6;
                 const int rem = U & 63;
-                const bool others = __ballot(T.mode == M_UNWIND || T.mode == M_DESCEND) != 0;
+                const bool others = sq_ballot(T.mode == M_UNWIND || T.mode == M_DESCEND) != 0;
                 if (rem && (!others || carry || rem >= A.flush_min)) ++nwin;
                 stamp(3);
                 for (int w = 0; w < nwin; ++w) {
@@ -830,7 +834,7 @@ __device__ __forceinline__ void trace_rays_body(const SceneView& S, const TraceA
                     }
                     stamp(5);
 #pragma unroll
-                    for (int k = 0; k < NT; ++k) { hmk[k] = __ballot(hit[k]); hm |= hmk[k]; if (PROFILE) pl_hit += (int)hit[k]; }
+                    for (int k = 0; k < NT; ++k) { hmk[k] = sq_ballot(hit[k]); hm |= hmk[k]; if (PROFILE) pl_hit += (int)hit[k]; }
                     while (hm) {                                                // accepted hits in leaf order: lane by lane, a lane's triangles in turn
                         const int l = __ffsll((long long)hm) - 1;
                         hm &= hm - 1;
@@ -855,14 +859,14 @@ __device__ __forceinline__ void trace_rays_body(const SceneView& S, const TraceA
                 continue;
             }
             const int c = (T.mode == M_LEAFQ) ? lf_cnt : 0;
-            if (__ballot(c > 0) == 0) continue;
+            if (sq_ballot(c > 0) == 0) continue;
             const int incl = wave_scan_add(c);                              // pairs of lanes 0..lane
             const int P = __builtin_amdgcn_readlane(incl, 63);              // pairs queued in the wave
             const int start = incl - c;                                     // this lane's first pair
             const int tb = lf_first - start;                                // triangle of pair p = p + tb
             int nwin = P >> 6;
             const int rem = P & 63;
-            const bool others = __ballot(T.mode == M_UNWIND || T.mode == M_DESCEND) != 0;
+            const bool others = sq_ballot(T.mode == M_UNWIND || T.mode == M_DESCEND) != 0;
             if (rem && (!others || carry || rem >= A.flush_min)) ++nwin;
             stamp(3);
             // KW windows per step: their LDS round trips (head table, owner pulls, index record, vertices) are issued
@@ -913,7 +917,7 @@ __device__ __forceinline__ void trace_rays_body(const SceneView& S, const TraceA
                 stamp(5);
 #pragma unroll
                 for (int k = 0; k < KW; ++k) {
-                    unsigned long long hm = __ballot(hit[k]);
+                    unsigned long long hm = sq_ballot(hit[k]);
                     if (PROFILE) pl_hit += hit[k];
                     while (hm) {                                            // accepted hits in pair order
                         const int l = __ffsll((long long)hm) - 1;
@@ -953,7 +957,7 @@ __device__ __forceinline__ void trace_rays_body(const SceneView& S, const TraceA
         if (PROFILE) ++pf_outer;
         const bool idle = (T.mode == M_DONE);
         if (idle && my_ray >= 0) { *reinterpret_cast<int2*>(A.org + my_ray) = make_int2(__float_as_int(T.R.t), T.R.tri); my_ray = -1; }
-        const unsigned long long m = __ballot(idle);
+        const unsigned long long m = sq_ballot(idle);
         if (m) {
             refill(m, idle);
             if (exhausted && m == ~0ull) break;
@@ -961,9 +965,9 @@ __device__ __forceinline__ void trace_rays_body(const SceneView& S, const TraceA
         // advance until (almost) every lane has a leaf to test or is finished
         for (;;) {
             const bool adv = (T.mode == M_DESCEND) || (T.mode == M_UNWIND);
-            const unsigned long long am = __ballot(adv);
+            const unsigned long long am = sq_ballot(adv);
             if (am == 0) break;
-            if (__popcll(am) <= A.straggler_lanes && __ballot(T.mode == M_LEAF) != 0) break;
+            if (__popcll(am) <= A.straggler_lanes && sq_ballot(T.mode == M_LEAF) != 0) break;
             if (PROFILE) { ++pf_adv; pl_unw += (T.mode == M_UNWIND); }
             if (T.mode == M_UNWIND) trav_unwind(T, N, G, stk, BLOCK);
             if (PROFILE) pl_desc += (T.mode == M_DESCEND);
@@ -1041,8 +1045,8 @@ struct sq_device_scene {
     int device = 0;
     SceneView view{};
     void* d_arena = nullptr;      // every d_* array below lives in this one allocation
-    void *d_branches = nullptr, *d_leaves = nullptr, *d_tris = nullptr, *d_mats = nullptr, *d_verts = nullptr, *d_trix = nullptr, *d_rbranch = nullptr, *d_emitters = nullptr, *d_tri_mat = nullptr, *d_surfs = nullptr, *d_cull_child = nullptr, *d_cull16 = nullptr, *d_rtail = nullptr;
-    int height = 0; bool small_index = false; int n_cu = 256;
+    void *d_branches = nullptr, *d_leaves = nullptr, *d_tris = nullptr, *d_mats = nullptr, *d_verts = nullptr, *d_trix = nullptr, *d_rbranch = nullptr, *d_emitters = nullptr, *d_tri_mat = nullptr, *d_surfs = nullptr, *d_cull_child = nullptr, *d_cull16 = nullptr, *d_rtail = nullptr, *d_branches_m5 = nullptr;
+    int height = 0; bool small_index = false; int n_cu = 256; int64_t n_grown = 0;
     // workspace (grow-only)
     Work work{}; void* d_work = nullptr; size_t work_bytes = 0; int64_t work_pixels = 0, work_slots = 0;
     // timing of the dominant kernel
@@ -1054,7 +1058,7 @@ struct sq_device_scene {
     // second stream of the overlapped schedule (launch_frame) and its event pool
     hipStream_t aux = nullptr; std::vector<hipEvent_t> events;
     int64_t opt_overlap = 0, opt_aux_blocks_per_cu = 0;
-    int64_t opt_pool = 1, opt_refill_min = 12, opt_flush_min = 40, opt_guided = 1, opt_primary_resident = 1, opt_pixel_major = -1, opt_cull = 1, opt_descend_extra = 2, opt_descend_lanes = 16, opt_primary_pooled = 0, opt_coresidency = 0, opt_trace_prio = 0, opt_aux_low_priority = 1, opt_aux_polite = 0;
+    int64_t opt_pool = 1, opt_refill_min = 12, opt_flush_min = 40, opt_guided = 1, opt_primary_resident = 1, opt_pixel_major = -1, opt_cull = 1, opt_descend_extra = 2, opt_descend_lanes = 16, opt_primary_pooled = 0, opt_coresidency = 0, opt_trace_prio = 0, opt_aux_low_priority = 1, opt_aux_polite = 0, opt_incremental = 1;
 };
 
 namespace {
@@ -1133,6 +1137,8 @@ extern "C" int sq_scene_upload(const sq_scene* sc, int32_t device, sq_device_sce
     }
     std::vector<DevBranch> br((size_t)nb);
     std::vector<int> br_axis((size_t)nb);
+    std::vector<uint32_t> br_grown((size_t)nb, 0u);     // kGrownLeft | kGrownRight (sq_scene.h), for the incremental slab test
+    bool incremental_ok = true;                         // no child interval is inverted anywhere in the tree
     std::vector<DevLeaf> lf((size_t)nl);
     std::vector<sq_bounds> box((size_t)n);
     box[0] = sc->root;
@@ -1145,6 +1151,11 @@ extern "C" int sq_scene_upload(const sq_scene* sc, int32_t device, sq_device_sce
         for (int c = 0; c < 3; ++c) { d.lo[c] = b.lo[c]; d.hi[c] = b.hi[c]; }
         d.lmax = d.lmax2 = nd.lmax; d.rmin = d.rmin2 = nd.rmin; br_axis[ref[(size_t)i]] = kind;
         d.left = ref[(size_t)i + 1]; d.right = ref[(size_t)nd.link];
+        {   // how the children's planes sit in this branch's interval on the split axis (NaN fails every comparison)
+            const float lo = b.lo[kind], hi = b.hi[kind];
+            if (!(lo <= hi) || !(lo <= nd.lmax) || !(nd.rmin <= hi)) incremental_ok = false;
+            br_grown[ref[(size_t)i]] = (nd.lmax > hi ? kGrownLeft : 0u) | (nd.rmin < lo ? kGrownRight : 0u);
+        }
         sq_bounds l = b, r = b;                          // src/BIH.hs:130-141
         l.hi[kind] = nd.lmax; r.lo[kind] = nd.rmin;
         box[(size_t)i + 1] = l; box[(size_t)nd.link] = r;
@@ -1238,7 +1249,7 @@ extern "C" int sq_scene_upload(const sq_scene* sc, int32_t device, sq_device_sce
                 const DevBranch& d = br[(size_t)i];
                 uint32_t* r = &rbranch[(size_t)i * 10];
                 std::memcpy(r, d.lo, 12); std::memcpy(r + 3, &d.lmax, 4); std::memcpy(r + 4, d.hi, 12); std::memcpy(r + 7, &d.rmin, 4);
-                r[8] = enc(d.left) | ((uint32_t)br_axis[(size_t)i] << 29); r[9] = enc(d.right);
+                r[8] = enc(d.left) | ((uint32_t)br_axis[(size_t)i] << 29); r[9] = enc(d.right) | (br_grown[(size_t)i] << 29);   // kAxisMask bits: axis | grown children
             }
             rroot = enc(ref[0]);
         } else { trix.clear(); }
@@ -1284,6 +1295,17 @@ extern "C" int sq_scene_upload(const sq_scene* sc, int32_t device, sq_device_sce
         }
         root_ref = enc(root_ref);
     }
+    // Streaming form: branch record + its children's binary16 culling boxes as ONE packed 80-byte record (SceneView::branches_m,
+    // HybridNodes::kMerged).  Measured at 64 spp, same process, as a launch option: 1M-triangle scene
+    // trace launches 23.04 -> 22.62 ms, 82k-triangle scene +-0; the same records padded to one 128-byte line each were 16-21 %
+    // SLOWER (26.7 / 23.1 ms): the form lives on what stays in L2, i.e. on the table's footprint, not on lines per visit
+    // (profiles/r03t_merged_branches_ab.txt)
+    std::vector<uint32_t> br_m5;
+    br_m5.assign((size_t)nb * 20, 0u);                    // (a scene without culling boxes keeps zeros there: they are never read)
+    for (int32_t b = 0; b < nb; ++b) {
+        std::memcpy(&br_m5[(size_t)b * 20], &br[(size_t)b], 48);
+        if (!cull16.empty()) std::memcpy(&br_m5[(size_t)b * 20 + 12], &cull16[(size_t)b * 8], 32);
+    }
     // Emissive triangles (for the last-bounce shortcut of sq_shade1).  Disabled (-1) when a material value is not
     // finite (then s*0 + e is not exactly +0 for non-emitters) or when the list is long enough to cost more than it saves.
     std::vector<int32_t> emitters; int32_t n_emitters = -1;
@@ -1324,6 +1346,7 @@ extern "C" int sq_scene_upload(const sq_scene* sc, int32_t device, sq_device_sce
     if (!cull_child.empty()) up(&s->d_cull_child, cull_child.data(), cull_child.size() * sizeof(float));
     if (!cull16.empty()) up(&s->d_cull16, cull16.data(), cull16.size() * sizeof(uint32_t));
     up(&s->d_rtail, rtail.data(), rtail.size() * sizeof(uint32_t));
+    if (!br_m5.empty()) up(&s->d_branches_m5, br_m5.data(), br_m5.size() * sizeof(uint32_t));
     {
         std::vector<unsigned char> staging(arena_bytes, 0);
         for (const Piece& pc : pieces) if (pc.bytes) std::memcpy(staging.data() + pc.off, pc.src, pc.bytes);
@@ -1351,6 +1374,9 @@ extern "C" int sq_scene_upload(const sq_scene* sc, int32_t device, sq_device_sce
     v.rbranch = (const uint32_t*)s->d_rbranch; v.rroot = rroot;
     v.emitters = (const int32_t*)s->d_emitters; v.n_emitters = n_emitters;
     v.cull_o2max = cull_limits[0]; v.cull_d2min = cull_limits[1]; v.cull_d2max = cull_limits[2];
+    v.incremental_ok = (incremental_ok && v.finite_geometry) ? 1 : 0;
+    v.branches_m = (const float4*)s->d_branches_m5;
+    s->n_grown = 0; for (uint32_t g : br_grown) s->n_grown += (g & 1u) + (g >> 1);
     v.cull_child = (const float4*)s->d_cull_child; v.cull_child16 = (const uint4*)s->d_cull16; v.rtail = (const uint4*)s->d_rtail;
     *out = s;
     return 0;
@@ -1464,6 +1490,7 @@ template <typename StackT>
 int launch_frame(sq_device_scene* s, const Frame& F, hipStream_t stream) {
     SceneView S = s->view;
     if (!s->opt_cull) S.cull_o2max = -1.0f;                            // no ray is inside the culling limits: every leaf is tested
+    if (!s->opt_incremental) S.incremental_ok = 0;                     // resident form: every branch step tests both children from the branch's own box
     const long long pixels = (long long)F.local_rows * F.h;
     const int stack_cap = std::max(S.height, 1);
     const size_t px_lds = (size_t)kBlock * stack_cap * sizeof(StackT);
@@ -1840,6 +1867,7 @@ extern "C" int sq_set_option(sq_device_scene* s, const char* key, int64_t value)
     if (!std::strcmp(key, "guided")) { if (value < 0 || value > 3) return sq_set_error("guided must be in 0..3"); s->opt_guided = value; return 0; }
     if (!std::strcmp(key, "primary_resident")) { s->opt_primary_resident = value ? 1 : 0; return 0; }
     if (!std::strcmp(key, "cull")) { s->opt_cull = value ? 1 : 0; return 0; }
+    if (!std::strcmp(key, "incremental")) { s->opt_incremental = value ? 1 : 0; return 0; }
     if (!std::strcmp(key, "primary_pooled")) { s->opt_primary_pooled = value != 0; return 0; }
     if (!std::strcmp(key, "coresidency")) { s->opt_coresidency = value != 0; return 0; }
     if (!std::strcmp(key, "aux_polite")) { if (value < 0 || value > 8) return sq_set_error("aux_polite must be in 0..8"); s->opt_aux_polite = value; return 0; }

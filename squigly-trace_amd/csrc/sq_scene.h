@@ -71,9 +71,27 @@ struct SceneView {
     const float4* cull_child; // streaming form: 4 quads per branch, the culling boxes (lo, hi) of its left and of its right child; or nullptr
     const uint4* rtail;       // resident form: (lmax, rmin, left word, right word) per branch, what a return into a branch needs
     const uint4* cull_child16; // 2 quads per branch, the same boxes as binary16 pairs (x, y, z, unused), left child then right; or nullptr
+    const float4* branches_m;  // streaming form: the 48-byte branch record and the 32 bytes of its children's binary16 culling boxes as ONE
+                               //   packed record of 5 quads (HybridNodes::kMerged): a visit touches 1.5 lines on average instead of 2.3
+    int32_t incremental_ok;    // 1: every child interval of the tree is regular or grown (kGrownLeft / kGrownRight) and the geometry is
+                               // finite: the resident form may carry (tmin, tmax) down the tree (trav_descend)
 };
 
 struct Hit { float t; int32_t tri; };   // tri < 0 : Nothing.  dist is derived from t on demand (hit_dist)
+
+// Wave ballot of a Bool.  HIP's __ballot takes an int, and the bool -> int -> (!= 0) round trip survives into the ISA as a
+// v_cndmask 0/1 + v_cmp_ne pair per call (two 4-cycle VALU instructions) wherever the predicate already lives in an SGPR
+// pair; the builtin takes the i1 as it is.  SQ_BALLOT_BUILTIN=0 restores __ballot (A/B).
+#ifndef SQ_BALLOT_BUILTIN
+#define SQ_BALLOT_BUILTIN 1
+#endif
+__device__ __forceinline__ unsigned long long sq_ballot(bool p) {
+#if SQ_BALLOT_BUILTIN
+    return __builtin_amdgcn_ballot_w64(p);
+#else
+    return __ballot(p);
+#endif
+}
 
 // intersectsBB (src/Geometry.hs:166-177) with df = 1/dir precomputed (the reference recomputes the same value)
 __device__ __forceinline__ bool slab(float lx, float ly, float lz, float hx, float hy, float hz, f3 o, f3 df) {
@@ -154,7 +172,7 @@ __device__ __forceinline__ bool moller_trumbore_flat(f3 o, f3 d, f3 v0, f3 e1, f
     // |a| < eps fails g1 whatever f is (eps > kRcpMidLo), so only a huge, infinite or NaN determinant needs the division;
     // the test is wave-uniform so that the common case pays no divergence
     float f;
-    if (__ballot(!(__builtin_fabsf(a) <= kRcpMidHi))) f = 1.0f / a; else f = rcp_midrange(a);
+    if (sq_ballot(!(__builtin_fabsf(a) <= kRcpMidHi))) f = 1.0f / a; else f = rcp_midrange(a);
 #else
     const float f = 1.0f / a;
 #endif
@@ -291,11 +309,16 @@ template <> struct StackTraits<uint32_t> { static constexpr uint32_t flag = 0x80
 // kLeafBit; the triangle source of the same kernel knows how to turn a leaf reference into a range.
 struct BranchData { v4f q0, q1; int axis; uint32_t left, right; };   // q0 = lo.xyz,lmax ; q1 = hi.xyz,rmin
 
-struct BranchTail { float lmax, rmin; int axis; uint32_t left, right; };   // what a return into a branch needs
+struct BranchTail { float lmax, rmin; int axis; uint32_t left, right; uint32_t grown; };   // what a return into a branch needs
 constexpr uint32_t kAxisMask = 0x60000000u;     // bits 30..29 of a branch's LEFT reference word: the split axis
+// Resident form, bits 30..29 of the RIGHT reference word: "the left / the right child's box GROWS", i.e. the plane that
+// replaces one of this branch's own (lmax for hi[axis], rmin for lo[axis], src/BIH.hs:130-141) lies outside this branch's box.
+// That happens where lmax = max + 0.001 or rmin = min - 0.001 (src/BIH.hs:92-95) passes a plane of the root box that no
+// ancestor has clipped yet (5 of scene.obj's 1278 children).  Used by the incremental slab test (trav_descend).
+constexpr uint32_t kGrownLeft = 1u, kGrownRight = 2u;
 __device__ __forceinline__ BranchTail unpack_tail(v4f q2) {
     const uint32_t l = __float_as_uint(q2.z);
-    return BranchTail{ q2.x, q2.y, (int)((l >> 29) & 3u), l & ~kAxisMask, __float_as_uint(q2.w) };
+    return BranchTail{ q2.x, q2.y, (int)((l >> 29) & 3u), l & ~kAxisMask, __float_as_uint(q2.w), 0u };
 }
 __device__ __forceinline__ BranchData unpack_branch(v4f q0, v4f q1, v4f q2) {
     const BranchTail t = unpack_tail(q2);
@@ -316,6 +339,7 @@ __device__ __forceinline__ bool cull_test32(const CullBoxes32& c, bool left, f3 
 }
 struct GlobalNodes {            // every branch read from HBM/L2
     static constexpr bool kBoxInRegisters = false;
+    static constexpr bool kIncremental = false;
     static constexpr bool kCull = true;
     const float4* g;
     const float4* cull; bool cull_on;
@@ -343,9 +367,10 @@ struct HybridNodes {            // first n_lds branches (top of the tree) in LDS
 #define SQ_BOX_IN_REGISTERS 0
 #endif
     static constexpr bool kBoxInRegisters = SQ_BOX_IN_REGISTERS != 0;
+    // (the incremental slab test below, ResidentNodes, was first built for this form in round 3: exact, and no faster,
+    // because this form follows its memory system and not its instruction count -- profiles/r03c_stream_incremental.txt)
+    static constexpr bool kIncremental = false;
     static constexpr bool kCull = true;
-    const SQ_LDS v4f* l; const float4* g; uint32_t n_lds;
-    const float4* cull; bool cull_on;
     // SQ_STREAM_CULL16 (default): the children's culling boxes as binary16 pairs (2 quads per branch, as in the resident form)
     // instead of fp32 (4 quads): a branch visit reads 5 quads instead of 7 and the table is half the size (4.2 MB instead of
     // 8.3 MB on the 1M-triangle scene).  Coarser boxes cull a little less (planes move outwards by up to 2^-10 of their
@@ -354,27 +379,47 @@ struct HybridNodes {            // first n_lds branches (top of the tree) in LDS
 #ifndef SQ_STREAM_CULL16
 #define SQ_STREAM_CULL16 1
 #endif
-    const uint4* cull16;
+    // SQ_STREAM_MERGED (needs SQ_STREAM_CULL16): the 48-byte branch record and the 32 bytes of its children's binary16 culling
+    // boxes come from ONE packed 80-byte record (SceneView::branches_m): 1.5 cache lines per visit on average instead of 2.3, and
+    // one table pointer in scalar registers instead of two (the kernel spills SGPRs).  A compile-time choice: as a launch option it
+    // cost three more SGPRs and a select per load, and the six-wave build lost 12 % to the extra spills
+    // (profiles/r03v_bisect_streaming.txt).
+#ifndef SQ_STREAM_MERGED
+#define SQ_STREAM_MERGED 1
+#endif
+    static constexpr bool kMerged = (SQ_STREAM_MERGED != 0) && (SQ_STREAM_CULL16 != 0);
+    static constexpr uint32_t kStride = kMerged ? 5u : 3u;      // quads per record in `g`
+    const SQ_LDS v4f* l; const float4* g; uint32_t n_lds;      // g = SceneView::branches_m (kMerged) or SceneView::branches
+    bool cull_on;
 #if SQ_STREAM_CULL16
+    const uint4* cull16;                                       // !kMerged: the culling boxes' own table
     struct CullBoxes { uint4 l, r; };
-    __device__ __forceinline__ CullBoxes cull_load(uint32_t parent) const { return CullBoxes{ cull16[2 * (size_t)parent], cull16[2 * (size_t)parent + 1] }; }
+    __device__ __forceinline__ CullBoxes cull_load(uint32_t parent) const {
+        if constexpr (kMerged) {
+            const float4* p = g + (size_t)parent * kStride;
+            const float4 a = p[3], c = p[4];
+            return CullBoxes{ uint4{ __float_as_uint(a.x), __float_as_uint(a.y), __float_as_uint(a.z), __float_as_uint(a.w) }, uint4{ __float_as_uint(c.x), __float_as_uint(c.y), __float_as_uint(c.z), __float_as_uint(c.w) } };
+        } else return CullBoxes{ cull16[2 * (size_t)parent], cull16[2 * (size_t)parent + 1] };
+    }
     __device__ __forceinline__ bool cull_test(const CullBoxes& c, bool left, f3 df, f3 nodf) const {
         const uint4 w = left ? c.l : c.r;
         return cull_slab_half(w.x, w.y, w.z, df, nodf);
     }
 #else
+    const float4* cull;
     using CullBoxes = CullBoxes32;
     __device__ __forceinline__ CullBoxes cull_load(uint32_t parent) const { return cull_load32(cull, parent); }
     __device__ __forceinline__ bool cull_test(const CullBoxes& c, bool left, f3 df, f3 nodf) const { return cull_test32(c, left, df, nodf); }
 #endif
     __device__ __forceinline__ BranchData load(uint32_t b) const {
         if (b < n_lds) return unpack_branch(l[3 * b], l[3 * b + 1], l[3 * b + 2]);
-        const float4 a = g[3 * b], c = g[3 * b + 1], d = g[3 * b + 2];
+        const float4* p = g + (size_t)b * kStride;
+        const float4 a = p[0], c = p[1], d = p[2];
         return unpack_branch(v4f{ a.x, a.y, a.z, a.w }, v4f{ c.x, c.y, c.z, c.w }, v4f{ d.x, d.y, d.z, d.w });
     }
     __device__ __forceinline__ BranchTail tail(uint32_t b) const {
         if (b < n_lds) return unpack_tail(l[3 * b + 2]);
-        const float4 d = g[3 * b + 2];
+        const float4 d = g[(size_t)b * kStride + 2];
         return unpack_tail(v4f{ d.x, d.y, d.z, d.w });
     }
 };
@@ -385,6 +430,12 @@ constexpr uint32_t kResAxisMask = kAxisMask;
 #ifndef SQ_RES_BOX_IN_REGISTERS
 #define SQ_RES_BOX_IN_REGISTERS 0
 #endif
+#ifndef SQ_RES_INCREMENTAL
+#define SQ_RES_INCREMENTAL 0      // measured and rejected in the resident form too (see kIncremental below)
+#endif
+#ifndef SQ_RES_TAIL_W
+#define SQ_RES_TAIL_W 0           // a return reads lmax and rmin as two 4-byte LDS reads instead of the two whole quads
+#endif
 struct ResidentNodes {
     // Round 1 read a branch's own box with every visit ("LDS reads are cheap and VALU is what binds").  After the pooled
     // windows and the culling boxes it is the number of memory instructions that the frame time follows, so the box can
@@ -392,8 +443,17 @@ struct ResidentNodes {
     // step then reads ONE 16-byte tail record (lmax, rmin, left word, right word) instead of two quads and a reference
     // pair; only a return re-reads the branch's own box (24 bytes, behind the tails).  Same 40 bytes per branch.
     static constexpr bool kBoxInRegisters = SQ_RES_BOX_IN_REGISTERS != 0;
+    // Incremental slab test (round 3, trav_descend / trav_unwind): a safe ray carries (tmin, tmax) of intersectsBB for the box
+    // of its current branch; a child's values follow from ONE new plane -- 2 fp32 operations and one min or max instead of
+    // 24 and 16 -- and a return into a branch computes the far child's pair from that branch's box.  The trace kernel is
+    // bound by VALU issue, and the two traversal slab tests were a third of a branch step's instructions.
+    // `incr`: the tree allows it (no inverted interval anywhere, finite geometry: checked at upload) and option "incremental".
+    static constexpr bool kIncremental = SQ_RES_INCREMENTAL != 0;
+    // LDS layout with one 16-byte tail record per branch (lmax, rmin, left word, right word) and the 24-byte (lo.xyz, hi.xyz)
+    // box records behind them; otherwise (lo, lmax) of all branches, then (hi, rmin) of all branches, then the reference pairs
+    static constexpr bool kTailLayout = kBoxInRegisters || kIncremental;
     // (lo, lmax) of all branches, then (hi, rmin) of all branches: a wave's read of either spreads over all 16 bank slots
-    // kBoxInRegisters: `quads` holds the tail records and `boxes` the 24-byte (lo.xyz, hi.xyz) records; quads_hi / refs unused
+    // kTailLayout: `quads` holds the tail records and `boxes` the 24-byte (lo.xyz, hi.xyz) records; quads_hi / refs unused
     const SQ_LDS v4f* quads; const SQ_LDS v4f* quads_hi;
     const SQ_LDS v2i* refs;       // 1 per branch
     const SQ_LDS v2f* boxes;
@@ -412,37 +472,57 @@ struct ResidentNodes {
     }
     __device__ __forceinline__ v4f q0(uint32_t b) const { return quads[b]; }
     __device__ __forceinline__ v4f q1(uint32_t b) const { return quads_hi[b]; }
+    // the branch's own traversal box, lo.xyz and hi.xyz (kTailLayout: three 8-byte reads)
+    __device__ __forceinline__ void box(uint32_t b, f3& lo, f3& hi) const {
+        if constexpr (kTailLayout) {
+            const v2f p0 = boxes[3 * b], p1 = boxes[3 * b + 1], p2 = boxes[3 * b + 2];
+            lo = sq::mk(p0.x, p0.y, p1.x); hi = sq::mk(p1.y, p2.x, p2.y);
+        } else {
+            const v4f a = q0(b), c = q1(b);
+            lo = sq::mk(a.x, a.y, a.z); hi = sq::mk(c.x, c.y, c.z);
+        }
+    }
     __device__ __forceinline__ BranchData load(uint32_t b) const {
-        if constexpr (kBoxInRegisters) {
+        if constexpr (kTailLayout) {
             const v4f t = quads[b];
             const v2f p0 = boxes[3 * b], p1 = boxes[3 * b + 1], p2 = boxes[3 * b + 2];
             const uint32_t l = __float_as_uint(t.z);
-            return BranchData{ v4f{ p0.x, p0.y, p1.x, t.x }, v4f{ p1.y, p2.x, p2.y, t.y }, (int)((l >> 29) & 3u), l & ~kResAxisMask, __float_as_uint(t.w) };
+            return BranchData{ v4f{ p0.x, p0.y, p1.x, t.x }, v4f{ p1.y, p2.x, p2.y, t.y }, (int)((l >> 29) & 3u), l & ~kResAxisMask, __float_as_uint(t.w) & ~kResAxisMask };
         }
         const v2i r = refs[b];
-        return BranchData{ q0(b), q1(b), (int)(((uint32_t)r.x >> 29) & 3u), (uint32_t)r.x & ~kResAxisMask, (uint32_t)r.y };
+        return BranchData{ q0(b), q1(b), (int)(((uint32_t)r.x >> 29) & 3u), (uint32_t)r.x & ~kResAxisMask, (uint32_t)r.y & ~kResAxisMask };
     }
 #ifndef SQ_RES_TAIL_GLOBAL
 #define SQ_RES_TAIL_GLOBAL 0      // measured: 64.2 ms per headline frame with the global tail against 62.5 ms with the three LDS reads (same run)
 #endif
     const uint4* rtail;           // global copy of (lmax, rmin, left word, right word) per branch: what a return needs, in one load
+    bool incr;
     __device__ __forceinline__ BranchTail tail(uint32_t b) const {
         if (SQ_RES_TAIL_GLOBAL) {   // one global load (10 KB table, L1) instead of three LDS reads: the LDS pipe is what binds
             const uint4 t = rtail[b];
-            return BranchTail{ __uint_as_float(t.x), __uint_as_float(t.y), (int)((t.z >> 29) & 3u), t.z & ~kResAxisMask, t.w };
+            return BranchTail{ __uint_as_float(t.x), __uint_as_float(t.y), (int)((t.z >> 29) & 3u), t.z & ~kResAxisMask, t.w & ~kResAxisMask, (t.w >> 29) & 3u };
         }
-        if constexpr (kBoxInRegisters) {
+        if constexpr (kTailLayout) {
             const v4f t = quads[b];
-            const uint32_t l = __float_as_uint(t.z);
-            return BranchTail{ t.x, t.y, (int)((l >> 29) & 3u), l & ~kResAxisMask, __float_as_uint(t.w) };
+            const uint32_t l = __float_as_uint(t.z), r = __float_as_uint(t.w);
+            return BranchTail{ t.x, t.y, (int)((l >> 29) & 3u), l & ~kResAxisMask, r & ~kResAxisMask, (r >> 29) & 3u };
         }
         const v2i r = refs[b];
-        return BranchTail{ q0(b).w, q1(b).w, (int)(((uint32_t)r.x >> 29) & 3u), (uint32_t)r.x & ~kResAxisMask, (uint32_t)r.y };
+#if SQ_RES_TAIL_W
+        const float lmax = reinterpret_cast<const SQ_LDS float*>(quads)[4 * b + 3], rmin = reinterpret_cast<const SQ_LDS float*>(quads_hi)[4 * b + 3];
+        return BranchTail{ lmax, rmin, (int)(((uint32_t)r.x >> 29) & 3u), (uint32_t)r.x & ~kResAxisMask, (uint32_t)r.y & ~kResAxisMask, ((uint32_t)r.y >> 29) & 3u };
+#endif
+        return BranchTail{ q0(b).w, q1(b).w, (int)(((uint32_t)r.x >> 29) & 3u), (uint32_t)r.x & ~kResAxisMask, (uint32_t)r.y & ~kResAxisMask, ((uint32_t)r.y >> 29) & 3u };
     }
 };
 
 // Triangle sources: (v0, e1, e2) of triangle i.  e1 = v1 - v0 and e2 = v2 - v0 are the reference's
 // edge1/edge2 (src/Geometry.hs:130-131) whether they were subtracted at upload or here.
+// SQ_STREAM_NT (timing experiment, bits unchanged): bit 0 = triangle runs of the streaming form are loaded with the
+// non-temporal hint (a triangle is read by the few rays that open its leaf: let the L2 keep the tree instead)
+#ifndef SQ_STREAM_NT
+#define SQ_STREAM_NT 0
+#endif
 struct GlobalTris {
     static constexpr bool kPairLoads = true;
     const float* t; const int2* leaves; bool packed, deep;   // deep: 8 triangles' loads in flight (scene beyond L2)
@@ -462,11 +542,20 @@ struct GlobalTris {
         constexpr int Q = (9 * N) / 4, R = (9 * N) % 4;
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
+#if (SQ_STREAM_NT & 1)
+            const f4u x = __builtin_nontemporal_load(reinterpret_cast<const f4u*>(p + 4 * q));
+#else
             const f4u x = *reinterpret_cast<const f4u*>(p + 4 * q);
+#endif
             w[4 * q] = x.x; w[4 * q + 1] = x.y; w[4 * q + 2] = x.z; w[4 * q + 3] = x.w;
         }
+#if (SQ_STREAM_NT & 1)
+        if constexpr (R >= 2) { const f2u x = __builtin_nontemporal_load(reinterpret_cast<const f2u*>(p + 4 * Q)); w[4 * Q] = x.x; w[4 * Q + 1] = x.y; }
+        if constexpr (R == 1 || R == 3) w[9 * N - 1] = __builtin_nontemporal_load(p + 9 * N - 1);
+#else
         if constexpr (R >= 2) { const f2u x = *reinterpret_cast<const f2u*>(p + 4 * Q); w[4 * Q] = x.x; w[4 * Q + 1] = x.y; }
         if constexpr (R == 1 || R == 3) w[9 * N - 1] = p[9 * N - 1];
+#endif
 #pragma unroll
         for (int k = 0; k < N; ++k) {
             const float* c = w + 9 * k;
@@ -573,7 +662,21 @@ struct Trav {
     f3 blo, bhi;        // NodeSrc::kBoxInRegisters: traversal box of the node `cur` (unused otherwise)
     bool cull;          // the ray is inside the limits of sq_cull_boxes: a node whose culling box it misses returns Nothing
     f3 nodf;            // -o * (1/d), for the culling slab test in FMA form
+    // NodeSrc::kIncremental, safe rays: tmin / tmax of intersectsBB (src/Geometry.hs:166-177) for the box of branch `cur`, valid
+    // while tvalid; otherwise the next branch step recomputes them from that branch's own box
+    float tn, tf; bool tvalid;
 };
+
+// tmin / tmax of the slab test of a box for a SAFE ray (finite o, d, 1/d, finite planes): the values the reference computes
+// (src/Geometry.hs:166-177), up to the sign of a zero (v_min / v_max against Haskell's min / max, see slab_fast), which no
+// comparison can see.
+__device__ __forceinline__ void slab_interval(f3 lo, f3 hi, f3 o, f3 df, float& tn, float& tf) {
+    const float t1 = (lo.x - o.x) * df.x, t2 = (hi.x - o.x) * df.x;
+    const float t3 = (lo.y - o.y) * df.y, t4 = (hi.y - o.y) * df.y;
+    const float t5 = (lo.z - o.z) * df.z, t6 = (hi.z - o.z) * df.z;
+    tn = vmax3(vmin(t1, t2), vmin(t3, t4), vmin(t5, t6));
+    tf = vmin3(vmax(t1, t2), vmax(t3, t4), vmax(t5, t6));
+}
 
 __device__ __forceinline__ void trav_begin(Trav& T, const SceneView& S, uint32_t root_ref, f3 o, f3 d) {
     T.o = o; T.d = d; T.df = sq::mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
@@ -587,6 +690,8 @@ __device__ __forceinline__ void trav_begin(Trav& T, const SceneView& S, uint32_t
     }
     T.blo = sq::mk(S.root_lo[0], S.root_lo[1], S.root_lo[2]); T.bhi = sq::mk(S.root_hi[0], S.root_hi[1], S.root_hi[2]);
     T.mode = (T.cur & kLeafBit) ? M_LEAF : M_DESCEND;
+    // incremental slab test: the root's pair (the same six products as slab() below; only meaningful for a safe ray)
+    slab_interval(T.blo, T.bhi, o, T.df, T.tn, T.tf); T.tvalid = true;
     if (T.mode == M_DESCEND &&
         !slab(S.root_lo[0], S.root_lo[1], S.root_lo[2], S.root_hi[0], S.root_hi[1], S.root_hi[2], o, T.df))
         T.mode = M_DONE;                                                // src/BIH.hs:112 at the root
@@ -601,11 +706,66 @@ __device__ __forceinline__ void trav_begin(Trav& T, const SceneView& S, uint32_t
 #ifndef SQ_DESCEND_PREFETCH
 #define SQ_DESCEND_PREFETCH 0
 #endif
+#ifndef SQ_UNIFORM_SAFE
+#define SQ_UNIFORM_SAFE 0
+#endif
+#ifndef SQ_CULL_ONE_REGION
+#define SQ_CULL_ONE_REGION 1      // 54.3 -> 53.85 ms per headline frame, same call, two rounds (profiles/r03r_ab_control_flow.txt)
+#endif
 struct BranchPf { uint32_t idx; BranchData B; ResidentNodes::CullBoxes cb; bool cb_ok; };
 
 // One Branch equation (src/BIH.hs:111-141).  Pre: mode == M_DESCEND.
 template <typename NodeSrc, typename StackT>
 __device__ __forceinline__ void trav_descend(Trav& T, const NodeSrc& N, SQ_LDS StackT* stk, int stride, BranchPf* pf = nullptr) {
+    if constexpr (NodeSrc::kIncremental) {
+        // Incremental slab test.  The box of a child is its parent's with ONE plane replaced (src/BIH.hs:130-141), and
+        // t(plane) = (plane - o_a) * (1/d_a), the very product intersectsBB forms, is monotone in the plane under
+        // round-to-nearest (non-decreasing for d_a > 0, non-increasing for d_a < 0).  For a safe ray (no NaN anywhere) and a
+        // REGULAR child -- the new plane lies within the parent's interval [lo_a, hi_a] on the split axis -- the child's
+        // per-axis (near, far) pair on that axis is therefore contained in the parent's, the other two axes are the
+        // parent's, and with t = t(new plane):
+        //     left child  [lo_a, lmax]:  d_a > 0: tmax' = min(tmax, t)   d_a < 0: tmin' = max(tmin, t)   (the other one unchanged)
+        //     right child [rmin, hi_a]:  d_a > 0: tmin' = max(tmin, t)   d_a < 0: tmax' = min(tmax, t)
+        // are the reference's values for the child bit for bit: a max / min over the three axes in which one term is replaced
+        // by one that is at least as tight.  A GROWN child (kGrownLeft / kGrownRight) has a box that contains its parent's; the
+        // parent passed `tmax > 0 && tmin < tmax` (or the ray would not be here), the child's tmin is no larger and its tmax
+        // no smaller, so the child passes too -- but its own pair is not derivable from the parent's: the ray is marked and
+        // recomputes it from that child's own box if it descends into it.  A return into a FAR frame computes the far child's
+        // pair from the branch's own box with the one plane replaced (trav_unwind), which is right for regular and grown
+        // children alike.  Trees with an inverted interval anywhere (never built by makeBIH; possible through the C-ABI) and
+        // unsafe rays take the plain path below.
+        if (N.incr && T.safe) {
+            typename NodeSrc::CullBoxes cbx;
+            const bool use_cull_i = T.cull && N.cull_on;
+            if (use_cull_i) cbx = N.cull_load(T.cur);                       // both children's culling boxes, requested first
+            const BranchTail B = N.tail(T.cur);
+            if (!T.tvalid) {                                                // rare: the ray descended into a grown child
+                f3 lo, hi; N.box(T.cur, lo, hi);
+                slab_interval(lo, hi, T.o, T.df, T.tn, T.tf);
+                T.tvalid = true;
+            }
+            const float oa = sq::axis_of(T.o, B.axis), dfa = sq::axis_of(T.df, B.axis);
+            const bool pos = sq::axis_of(T.d, B.axis) > 0;                  // leftToRight, src/BIH.hs:127
+            const float tl = (B.lmax - oa) * dfa, tr = (B.rmin - oa) * dfa;
+            const float tnL = pos ? T.tn : vmax(T.tn, tl), tfL = pos ? vmin(T.tf, tl) : T.tf;
+            const float tnR = pos ? vmax(T.tn, tr) : T.tn, tfR = pos ? T.tf : vmin(T.tf, tr);
+            const bool gL = (B.grown & kGrownLeft) != 0, gR = (B.grown & kGrownRight) != 0;
+            bool iL = gL || (tfL > 0 && tnL < tfL), iR = gR || (tfR > 0 && tnR < tfR);
+            if (use_cull_i) { iL = iL && N.cull_test(cbx, true, T.df, T.nodf); iR = iR && N.cull_test(cbx, false, T.df, T.nodf); }
+            bool went_left;
+            if (iL && iR) {
+                stk[T.sp * stride] = (StackT)T.cur; ++T.sp;                 // FAR(cur)
+                went_left = pos;
+            } else if (iL) went_left = true;
+            else if (iR) went_left = false;
+            else { T.R.tri = -1; T.mode = M_UNWIND; return; }               // src/BIH.hs:119
+            T.cur = went_left ? B.left : B.right;
+            T.tn = went_left ? tnL : tnR; T.tf = went_left ? tfL : tfR;
+            T.tvalid = !(went_left ? gL : gR);
+            if (T.cur & kLeafBit) T.mode = M_LEAF;
+            return;
+        }
+    }
     v4f q0, q1; int ax; uint32_t left, right;
     constexpr bool kPf = (SQ_DESCEND_PREFETCH != 0) && std::is_same<NodeSrc, ResidentNodes>::value;
     bool have = false;
@@ -647,7 +807,14 @@ __device__ __forceinline__ void trav_descend(Trav& T, const NodeSrc& N, SQ_LDS S
     const float lhx = ax == 0 ? lmax : q1.x, lhy = ax == 1 ? lmax : q1.y, lhz = ax == 2 ? lmax : q1.z;
     const float rlx = ax == 0 ? rmin : q0.x, rly = ax == 1 ? rmin : q0.y, rlz = ax == 2 ? rmin : q0.z;
     bool iL, iR;
+#if SQ_UNIFORM_SAFE
+    // slab() is right for every ray and slab_fast() for safe ones: the choice is made per WAVE (one scalar branch instead of
+    // a divergent if / else with its exec-mask bookkeeping -- the trace kernel's time follows its scalar and branch
+    // instructions as much as its VALU instructions, profiles/r03q_pmc_incremental*.txt)
+    if (sq_ballot(!T.safe) == 0) {
+#else
     if (T.safe) {
+#endif
         iL = slab_fast(q0.x, q0.y, q0.z, lhx, lhy, lhz, T.o, T.df);
         iR = slab_fast(rlx, rly, rlz, q1.x, q1.y, q1.z, T.o, T.df);
     } else {
@@ -658,7 +825,13 @@ __device__ __forceinline__ void trav_descend(Trav& T, const NodeSrc& N, SQ_LDS S
         // With a child known to return Nothing the Branch equation reduces to the other child's value, whatever isClose says
         // (src/BIH.hs:113-119: near = Nothing -> far; far = Nothing -> near in all three alternatives), i.e. to the
         // single-child equations, and no frame is pushed: "intersects" below means "intersects and may hold a hit".
+#if SQ_CULL_ONE_REGION
+        // both tests for every lane that loaded the boxes, in one exec region (no short-circuit: nearly every wave has a lane
+        // that needs each of them anyway)
+        if (use_cull) { const bool cL = N.cull_test(cb, true, T.df, T.nodf), cR = N.cull_test(cb, false, T.df, T.nodf); iL = iL & cL; iR = iR & cR; }
+#else
         if (use_cull) { iL = iL && N.cull_test(cb, true, T.df, T.nodf); iR = iR && N.cull_test(cb, false, T.df, T.nodf); }
+#endif
     }
     bool went_left;
     if (iL && iR) {
@@ -760,13 +933,17 @@ __device__ __forceinline__ void trav_unwind(Trav& T, const NodeSrc& N, const Tri
     if constexpr (NodeSrc::kBoxInRegisters) {
         const BranchData D = N.load(e);                                 // this branch's own box again; the far child's follows below
         T.blo = sq::mk(D.q0.x, D.q0.y, D.q0.z); T.bhi = sq::mk(D.q1.x, D.q1.y, D.q1.z);
-        B = BranchTail{ D.q0.w, D.q1.w, D.axis, D.left, D.right };
+        B = BranchTail{ D.q0.w, D.q1.w, D.axis, D.left, D.right, 0u };
     } else B = N.tail(e);
     const int ax = B.axis;
     const bool l2r = sq::axis_of(T.d, ax) > 0;
     if (T.R.tri >= 0) {
         const float p = sq::axis_of(T.o, ax) + T.R.t * sq::axis_of(T.d, ax);   // projectToAxis ax (intersectPoint near)
+#if SQ_BALLOT_BUILTIN
+        const bool close = (l2r & (p < B.rmin)) | (!l2r & (p > B.lmax));   // isClose, src/BIH.hs:121-123 (mask arithmetic, no select of Bools)
+#else
         const bool close = l2r ? (p < B.rmin) : (p > B.lmax);           // isClose, src/BIH.hs:121-123
+#endif
         if (close) return;                                              // src/BIH.hs:114: the branch returns near
         stk[T.sp * stride] = (StackT)((uint32_t)T.R.tri | flag);        // COMBINE(R)
         T.csp = T.sp; T.ct = T.R.t; ++T.sp;
@@ -775,6 +952,17 @@ __device__ __forceinline__ void trav_unwind(Trav& T, const NodeSrc& N, const Tri
     if constexpr (NodeSrc::kBoxInRegisters) {
         if (l2r) { if (ax == 0) T.blo.x = B.rmin; else if (ax == 1) T.blo.y = B.rmin; else T.blo.z = B.rmin; }
         else     { if (ax == 0) T.bhi.x = B.lmax; else if (ax == 1) T.bhi.y = B.lmax; else T.bhi.z = B.lmax; }
+    }
+    if constexpr (NodeSrc::kIncremental) {
+        // incremental slab test: the far child's (tmin, tmax) from its own box = this branch's box with lo[ax] := rmin (right
+        // child) or hi[ax] := lmax (left child), src/BIH.hs:130-141 -- regular or grown, the same expressions as the reference
+        if (N.incr && T.safe && !(T.cur & kLeafBit)) {
+            f3 lo, hi; N.box(e, lo, hi);
+            const float rx = (l2r && ax == 0) ? B.rmin : lo.x, ry = (l2r && ax == 1) ? B.rmin : lo.y, rz = (l2r && ax == 2) ? B.rmin : lo.z;
+            const float hx = (!l2r && ax == 0) ? B.lmax : hi.x, hy = (!l2r && ax == 1) ? B.lmax : hi.y, hz = (!l2r && ax == 2) ? B.lmax : hi.z;
+            slab_interval(sq::mk(rx, ry, rz), sq::mk(hx, hy, hz), T.o, T.df, T.tn, T.tf);
+            T.tvalid = true;
+        } else T.tvalid = false;
     }
     // (no culling test here: a FAR frame is only pushed for a far child whose culling box the ray hits, trav_descend)
     T.mode = (T.cur & kLeafBit) ? M_LEAF : M_DESCEND;

@@ -248,6 +248,8 @@ def run_case(seed, kinds=12):
         if BIG:            # the overlapped schedules' scheduling options (BIG draws `overlap` below)
             knobs["aux_polite"] = ((seed * 2246822519) >> 5) % 3
             knobs["trace_prio"] = (((seed * 3266489917) >> 4) % 2) * 2
+    if seed >= 40000000:   # second round-3 campaign (merged branch records in the streaming form, one-region culling tests, ballot builtin)
+        knobs["lds_node_kb"] = (0, 1, 4, 32)[((seed * 40503) >> 5) % 4]
     for kv in os.environ.get("SQ_FUZZ_FORCE", "").split(","):          # e.g. SQ_FUZZ_FORCE=primary_pooled=1,cull=0
         if "=" in kv:
             knobs[kv.split("=")[0]] = int(kv.split("=")[1])

@@ -507,7 +507,8 @@ def test_pooled_and_classic_trace_kernels_agree(sqt, product_scene, oracle_scene
                      {"pool": 1, "resident": 0, "pixel_major": 1}, {"pool": 1, "resident": 1, "pixel_major": 1},
                      {"pool": 1, "resident": 1, "pixel_major": 0, "cull": 0}, {"pool": 0, "resident": 0, "cull": 0},
                      {"pool": 1, "resident": 1, "cull": 1, "descend_extra": 0}, {"pool": 1, "resident": 1, "descend_extra": 7, "descend_lanes": 1},
-                     {"pool": 1, "resident": 0, "descend_extra": 3, "descend_lanes": 33}):
+                     {"pool": 1, "resident": 0, "descend_extra": 3, "descend_lanes": 33},
+                     {"pool": 1, "resident": 0, "lds_node_kb": 1}, {"pool": 0, "resident": 0, "lds_node_kb": 0, "cull": 1}):
             for k, v in opts.items():
                 dev.set_option(k, v)
             avg, rgb = dev.render_rows(cam, n, w, h)
@@ -515,7 +516,8 @@ def test_pooled_and_classic_trace_kernels_agree(sqt, product_scene, oracle_scene
             assert np.array_equal(bits(avg.cpu().numpy()), bits(o)), opts
             assert np.array_equal(rgb.cpu().numpy(), o8), opts
     finally:
-        for k, v in {"pool": 1, "refill_min": 12, "flush_min": 40, "resident": 1, "pixel_major": -1, "cull": 1, "descend_extra": 2, "descend_lanes": 16}.items():
+        for k, v in {"pool": 1, "refill_min": 12, "flush_min": 40, "resident": 1, "pixel_major": -1, "cull": 1, "descend_extra": 2, "descend_lanes": 16,
+                     "lds_node_kb": 32}.items():
             dev.set_option(k, v)
 
 
