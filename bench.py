@@ -40,8 +40,14 @@ CONFIGS = {"c2": (1920, 1080, 256), "c4": (3840, 2160, 1024)}   # first number =
 # Measured again in round 3 (profiles/r03a_op_rate.txt): v_add/sub 2.50, v_mul 2.5-2.7, v_mov 2.25, v_xor 2.33, v_fma 3.76, v_cmp 4.1-4.35,
 # v_min/max 4.40, v_max3/min3 4.57, integer mix 4.22, v_fma_mix 4.39, v_cvt 4.11, v_lshl_add_u64 6.05, v_rcp 8.54; 1, 2 and 8 waves per
 # SIMD price the 4-cycle classes the same (4.1-4.5), so these are pipeline rates, not a shortage of waves.
-VALU_PRICE = {"ADD_F32": 2.5, "MUL_F32": 2.6, "FMA_F32": 3.8, "TRANS_F32": 8.5, "INT32": 4.2, "INT64": 6.0, "CVT": 4.1,
+# Per opcode (tools/ubench/op_rate2.hip, profiles/r03p_op_rate2.txt): the 32-bit integer class is not one price -- v_and / v_or / v_xor /
+# v_not / v_add_u32 / v_sub_u32 / v_lshrrev_b32 issue at 2.2-2.5 cycles, v_lshlrev_b32 / v_bfe / v_add3 / v_mul_lo / v_perm / v_bfi / v_bcnt /
+# lshl_add / integer min-max at 4.2-4.5; two thirds of the shipped trace kernel's integer instructions are of the fast kind (static
+# count), hence 3.1 with 2.5 / 4.3 as its bounds.  A fast-class instruction that reads an SGPR operand costs 4.4 (v_mul_f32 v, s, v), which
+# no counter shows: the `high` bound is the honest one wherever the compiler keeps wave-uniform values in SGPRs.
+VALU_PRICE = {"ADD_F32": 2.5, "MUL_F32": 2.6, "FMA_F32": 3.8, "TRANS_F32": 8.5, "INT32": 3.1, "INT64": 6.0, "CVT": 4.1,
               "ADD_F64": 4.2, "MUL_F64": 4.2, "FMA_F64": 4.2}
+VALU_PRICE_INT32 = (2.5, 3.1, 4.3)     # low / point / high of the 32-bit integer class (see above)
 VALU_PRICE_OTHER = (2.3, 3.6, 4.4)     # low (all moves), point, high (all compares / min-max / DPP / lane reads)
 
 
@@ -52,15 +58,16 @@ def valu_mix_weighted(p, secs):
         return None
     classed = {k: float(p.get("SQ_INSTS_VALU_" + k, 0.0)) for k in VALU_PRICE}
     other = max(0.0, float(p["SQ_INSTS_VALU"]) - sum(classed.values()))
-    base = sum(classed[k] * VALU_PRICE[k] for k in VALU_PRICE)
+    base = sum(classed[k] * VALU_PRICE[k] for k in VALU_PRICE if k != "INT32")
     simd_cycles = N_SIMD * CLOCK_HZ * secs
-    lo, mid, hi = ((base + other * c) / simd_cycles for c in VALU_PRICE_OTHER)
+    lo, mid, hi = ((base + classed["INT32"] * ci + other * c) / simd_cycles for ci, c in zip(VALU_PRICE_INT32, VALU_PRICE_OTHER))
     return {"value": round(mid, 3), "low": round(lo, 3), "high": round(hi, 3),
             "fp32_add_mul_fma_share": round((classed["ADD_F32"] + classed["MUL_F32"] + classed["FMA_F32"]) / float(p["SQ_INSTS_VALU"]), 3),
             "unclassed_share": round(other / float(p["SQ_INSTS_VALU"]), 3),
-            "formula": "sum over SQ_INSTS_VALU_<class> of count x cycles-per-instruction-per-SIMD (tools/ubench/op_rate.hip, 4 waves per SIMD: "
-                       "add 2.5, mul 2.6, fma 3.8, transcendental 8.5, int32 4.2, int64 6.0, cvt 4.1, f64 4.2; unclassed = compares, min/max, selects, "
-                       "moves, DPP, lane reads at 2.3 (low) / 3.6 / 4.4 (high)) / (1024 SIMDs x 2.4 GHz x kernel seconds)"}
+            "formula": "sum over SQ_INSTS_VALU_<class> of count x cycles-per-instruction-per-SIMD (tools/ubench/op_rate.hip and op_rate2.hip, 4 waves "
+                       "per SIMD: add 2.5, mul 2.6, fma 3.8, transcendental 8.5, int32 2.5 (low) / 3.1 / 4.3 (high: and/or/add/sub/lshr cost 2.5, "
+                       "lshl/bfe/mul/perm 4.3), int64 6.0, cvt 4.1, f64 4.2; unclassed = compares, min/max, selects, moves, DPP, lane reads at "
+                       "2.3 (low) / 3.6 / 4.4 (high)) / (1024 SIMDs x 2.4 GHz x kernel seconds)"}
 
 
 def alg_bytes(c, spp):
