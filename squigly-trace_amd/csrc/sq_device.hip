@@ -733,6 +733,8 @@ __device__ __forceinline__ void trace_rays_body(const SceneView& S, const TraceA
         // leaf order, with the very comparison of the one-lane leaf loop (minimumBy's rule, src/BIH.hs:105-109) --
         // the arithmetic of mollerTrumbore does not depend on the lane that runs it.
         constexpr int KW = kPoolWindows;
+        constexpr bool kFlat = RESIDENT && !PROFILE && (SQ_FLAT_STEPS != 0) && (SQ_DESCEND_PREFETCH == 0) && !ResidentNodes::kBoxInRegisters && !ResidentNodes::kIncremental;
+        bool flat_ok = false;               // wave-uniform (kFlat): every ray of the wave is safe and the scene has culling boxes
         SQ_LDS uint8_t* tab = to_lds<uint8_t>(lds + L.tab) + (threadIdx.x >> 6) * (64 * KW);   // this wave's window-head tables
         for (int k = 0; k < KW; ++k) tab[k * 64 + lane] = 0;
         const int lane_tag = lane * 4 + 1;  // a lane's mark in the head table: non-zero, grows with the lane, and is its ds_bpermute address
@@ -750,7 +752,11 @@ __device__ __forceinline__ void trace_rays_body(const SceneView& S, const TraceA
             if (idle && my_ray >= 0) { *reinterpret_cast<int2*>(A.org + my_ray) = make_int2(__float_as_int(T.R.t), T.R.tri); my_ray = -1; }
             const unsigned long long m = sq_ballot(idle);
             if (m) {
-                if (__popcll(m) >= A.refill_min || m == ~0ull) refill(m, idle);
+                if (__popcll(m) >= A.refill_min || m == ~0ull) {
+                    refill(m, idle);
+                    // the flat steps are for waves whose rays are all safe (a ray's flag only changes here) in scenes with culling boxes
+                    if constexpr (kFlat) flat_ok = N.cull_on && sq_ballot(T.mode != M_DONE && !T.safe) == 0;
+                }
                 if (exhausted && m == ~0ull) break;
             }
             stamp(0);
@@ -766,9 +772,26 @@ __device__ __forceinline__ void trace_rays_body(const SceneView& S, const TraceA
             __builtin_amdgcn_s_setprio(SQ_SETPRIO & 3);
 #endif
             if (PROFILE) pl_unw += (T.mode == M_UNWIND);
+            if constexpr (kFlat) {
+                // the return step with three exec regions (the step, COMBINE, FAR) instead of six nested ones: DONE, the pop and the
+                // kind of the popped frame are decided by selects, the FAR half is trav_unwind_far_flat
+                if (T.mode == M_UNWIND) {
+                    constexpr uint32_t flag = StackTraits<StackT>::flag;
+                    const bool done = T.sp == 0;
+                    T.sp -= done ? 0 : 1;
+                    const uint32_t e = stk[T.sp * BLOCK];                       // (slot 0, unused, for a ray that is done)
+                    const bool is_combine = !done && (e & flag) != 0, is_far = !done && (e & flag) == 0;
+                    if (is_combine) trav_unwind_combine<TriSrc, StackT>(T, G, e);
+                    if (is_far) trav_unwind_far_flat<StackT>(T, N, stk, BLOCK, e);
+                    T.mode = done ? M_DONE : T.mode;
+                }
+            } else
             if (T.mode == M_UNWIND) trav_unwind(T, N, G, stk, BLOCK, PROFILE ? &prof : nullptr);
             stamp(1);
             if (PROFILE) pl_desc += (T.mode == M_DESCEND);
+            if constexpr (kFlat) {
+                if (T.mode == M_DESCEND) { if (flat_ok) trav_descend_flat<StackT>(T, N, stk, BLOCK); else trav_descend(T, N, stk, BLOCK, &pf); }
+            } else
             if (T.mode == M_DESCEND) trav_descend(T, N, stk, BLOCK, &pf);
             // With the culling boxes a ray takes four branch steps per leaf it opens: lanes that are still descending take up
             // to `descend_extra` more steps in this iteration (while at least `descend_lanes` of them are), instead of paying a
@@ -776,6 +799,9 @@ __device__ __forceinline__ void trace_rays_body(const SceneView& S, const TraceA
             for (int x = 0; x < A.descend_extra; ++x) {
                 if (__popcll(sq_ballot(T.mode == M_DESCEND)) < A.descend_lanes) break;
                 if (PROFILE) pl_desc += (T.mode == M_DESCEND);
+                if constexpr (kFlat) {
+                    if (T.mode == M_DESCEND) { if (flat_ok) trav_descend_flat<StackT>(T, N, stk, BLOCK); else trav_descend(T, N, stk, BLOCK, &pf); }
+                } else
                 if (T.mode == M_DESCEND) trav_descend(T, N, stk, BLOCK, &pf);
             }
             stamp(2);

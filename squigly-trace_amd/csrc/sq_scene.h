@@ -907,6 +907,24 @@ __device__ __forceinline__ void trav_leaf(Trav& T, const TriSrc& G) {
     T.mode = M_UNWIND;
 }
 
+// The COMBINE half of a return: the popped frame `e` holds the hit the near child had returned; R is the far child's.
+// minimumByMay over [near, far] (src/BIH.hs:115,120).  T.sp already points at the popped frame.
+template <typename TriSrc, typename StackT>
+__device__ __forceinline__ void trav_unwind_combine(Trav& T, const TriSrc& G, uint32_t e, TravProf* prof = nullptr) {
+    constexpr uint32_t flag = StackTraits<StackT>::flag;
+    const int32_t ntri = (int32_t)(e & ~flag);
+    float nt = T.ct;
+    if (prof) ++prof->combine;
+    if (T.csp != T.sp) {                                                // not the cached (newest) frame: same bits from MT
+        if (prof) { ++prof->recompute_lanes; prof->recompute_waves += first_active_lane(); }
+        f3 v0, e1, e2;
+        G.get(ntri, v0, e1, e2);
+        (void)moller_trumbore(T.o, T.d, v0, e1, e2, nt);
+    }
+    T.csp = -1;
+    if (prof && T.R.tri >= 0 && !(!(nt > T.R.t) && T.R.t < __builtin_inff() && T.safe)) { ++prof->slowcmp_lanes; prof->slowcmp_waves += first_active_lane(); }
+    if (T.R.tri < 0 || !dist_gt(T.o, T.d, nt, T.R.t, T.safe)) { T.R.t = nt; T.R.tri = ntri; }   // ties keep near
+}
 // Return to the caller of the call that just produced R: pop one frame.  Pre: mode == M_UNWIND.
 template <typename NodeSrc, typename TriSrc, typename StackT>
 __device__ __forceinline__ void trav_unwind(Trav& T, const NodeSrc& N, const TriSrc& G, SQ_LDS StackT* stk, int stride, TravProf* prof = nullptr) {
@@ -914,21 +932,7 @@ __device__ __forceinline__ void trav_unwind(Trav& T, const NodeSrc& N, const Tri
     if (T.sp == 0) { T.mode = M_DONE; return; }
     --T.sp;
     const uint32_t e = stk[T.sp * stride];
-    if (e & flag) {                                                     // minimumByMay over [near, far] (src/BIH.hs:115,120)
-        const int32_t ntri = (int32_t)(e & ~flag);
-        float nt = T.ct;
-        if (prof) ++prof->combine;
-        if (T.csp != T.sp) {                                            // not the cached (newest) frame: same bits from MT
-            if (prof) { ++prof->recompute_lanes; prof->recompute_waves += first_active_lane(); }
-            f3 v0, e1, e2;
-            G.get(ntri, v0, e1, e2);
-            (void)moller_trumbore(T.o, T.d, v0, e1, e2, nt);
-        }
-        T.csp = -1;
-        if (prof && T.R.tri >= 0 && !(!(nt > T.R.t) && T.R.t < __builtin_inff() && T.safe)) { ++prof->slowcmp_lanes; prof->slowcmp_waves += first_active_lane(); }
-        if (T.R.tri < 0 || !dist_gt(T.o, T.d, nt, T.R.t, T.safe)) { T.R.t = nt; T.R.tri = ntri; }   // ties keep near
-        return;
-    }
+    if (e & flag) { trav_unwind_combine<TriSrc, StackT>(T, G, e, prof); return; }
     BranchTail B;                                                       // back in branch e: its near child returned R
     if constexpr (NodeSrc::kBoxInRegisters) {
         const BranchData D = N.load(e);                                 // this branch's own box again; the far child's follows below
@@ -966,6 +970,65 @@ __device__ __forceinline__ void trav_unwind(Trav& T, const NodeSrc& N, const Tri
     }
     // (no culling test here: a FAR frame is only pushed for a far child whose culling box the ray hits, trav_descend)
     T.mode = (T.cur & kLeafBit) ? M_LEAF : M_DESCEND;
+}
+
+
+// ---- "flat" branch and return steps (resident form, pooled kernel; SQ_FLAT_STEPS) ----------------------------------------------
+// The same equations as trav_descend / the FAR half of trav_unwind, written as ONE exec region each: every decision is a select on
+// values computed for all lanes of the step, and the two stack stores are unconditional (a store that the reference's control flow
+// would not make lands above the top of the stack or on the frame that was just popped, where nothing reads it).  Round 3 measured
+// that this kernel's time follows its scalar / exec-mask instructions as much as its VALU instructions: the nested
+// ifs of the plain forms cost about three scalar or branch instructions per nesting level and execution.
+// Preconditions, checked per WAVE by the caller: every lane taking the step has a safe ray (slab_fast is exact for it), and the
+// scene has culling boxes (N.cull_on).  Arithmetic: expression for expression that of the plain forms.
+#ifndef SQ_FLAT_STEPS
+#define SQ_FLAT_STEPS 1
+#endif
+template <typename StackT>
+__device__ __forceinline__ void trav_descend_flat(Trav& T, const ResidentNodes& N, SQ_LDS StackT* stk, int stride) {
+    const ResidentNodes::CullBoxes cb = N.cull_load(T.cur);             // both children's culling boxes, requested first
+    const BranchData B = N.load(T.cur);
+    const v4f q0 = B.q0, q1 = B.q1; const int ax = B.axis;
+    const float lmax = q0.w, rmin = q1.w;
+    // left = bbox with hi[ax] := lmax ; right = bbox with lo[ax] := rmin   (src/BIH.hs:130-141)
+    const float lhx = ax == 0 ? lmax : q1.x, lhy = ax == 1 ? lmax : q1.y, lhz = ax == 2 ? lmax : q1.z;
+    const float rlx = ax == 0 ? rmin : q0.x, rly = ax == 1 ? rmin : q0.y, rlz = ax == 2 ? rmin : q0.z;
+    const bool sL = slab_fast(q0.x, q0.y, q0.z, lhx, lhy, lhz, T.o, T.df);
+    const bool sR = slab_fast(rlx, rly, rlz, q1.x, q1.y, q1.z, T.o, T.df);
+    const bool cL = N.cull_test(cb, true, T.df, T.nodf), cR = N.cull_test(cb, false, T.df, T.nodf);
+    // (logical operators on values that are already computed: they stay i1 mask arithmetic in scalar registers, where `|` / `&`
+    // on bools are integer operations on 0 / 1 words in vector registers)
+    const bool nocull = !T.cull;                                        // a ray outside the lemma's limits visits what the reference visits
+    const bool iL = sL && (cL || nocull), iR = sR && (cR || nocull);
+    const bool both = iL && iR, any = iL || iR;
+    const bool l2r = sq::axis_of(T.d, ax) > 0;                          // src/BIH.hs:127
+    stk[T.sp * stride] = (StackT)T.cur;                                 // FAR(cur) if both children are visited; else a dead word above the top
+    T.sp += both ? 1 : 0;
+    const bool went_left = (both && l2r) || (!both && iL);
+    const uint32_t next = went_left ? B.left : B.right;
+    T.cur = any ? next : T.cur;
+    T.R.tri = any ? T.R.tri : -1;                                       // src/BIH.hs:119: neither child -> Nothing
+    T.mode = any ? ((next & kLeafBit) ? M_LEAF : M_DESCEND) : M_UNWIND;
+}
+// The FAR half of a return (the popped frame is a branch whose near child returned R).  Pre: mode == M_UNWIND, the popped word `e`
+// has no COMBINE flag; T.sp already points at the popped frame.
+template <typename StackT>
+__device__ __forceinline__ void trav_unwind_far_flat(Trav& T, const ResidentNodes& N, SQ_LDS StackT* stk, int stride, uint32_t e) {
+    constexpr uint32_t flag = StackTraits<StackT>::flag;
+    const BranchTail B = N.tail(e);
+    const int ax = B.axis;
+    const float da = sq::axis_of(T.d, ax);
+    const bool l2r = da > 0;
+    const bool hit = T.R.tri >= 0;
+    const float p = sq::axis_of(T.o, ax) + T.R.t * da;                  // projectToAxis ax (intersectPoint near); unused without a hit
+    const bool close = hit && ((l2r && p < B.rmin) || (!l2r && p > B.lmax));   // isClose, src/BIH.hs:121-123: the branch returns near
+    const bool push = hit && !close;                                    // COMBINE(R) (src/BIH.hs:115,120)
+    stk[T.sp * stride] = (StackT)((uint32_t)T.R.tri | flag);            // lands on the frame just popped: dead unless pushed
+    T.csp = push ? T.sp : T.csp; T.ct = push ? T.R.t : T.ct;
+    T.sp += push ? 1 : 0;
+    const uint32_t far = l2r ? B.right : B.left;
+    T.cur = close ? T.cur : far;
+    T.mode = close ? M_UNWIND : ((far & kLeafBit) ? M_LEAF : M_DESCEND);
 }
 
 // Whole query, one ray per lane (used where rays of a wave are coherent: primary and shadow rays).
