@@ -749,8 +749,8 @@ __device__ __forceinline__ void trace_rays_body(const SceneView& S, const TraceA
         for (;;) {
             if (PROFILE) ++pf_adv;
             const bool idle = (T.mode == M_DONE);
+            const unsigned long long m = sq_ballot(idle);       // before the store's exec region: the compare's mask IS the ballot
             if (idle && my_ray >= 0) { *reinterpret_cast<int2*>(A.org + my_ray) = make_int2(__float_as_int(T.R.t), T.R.tri); my_ray = -1; }
-            const unsigned long long m = sq_ballot(idle);
             if (m) {
                 if (__popcll(m) >= A.refill_min || m == ~0ull) {
                     refill(m, idle);
@@ -808,6 +808,12 @@ __device__ __forceinline__ void trace_rays_body(const SceneView& S, const TraceA
 #ifdef SQ_SETPRIO      // ... and in its leaf scan and pair windows (bits 3..2)
             __builtin_amdgcn_s_setprio((SQ_SETPRIO >> 2) & 3);
 #endif
+            if constexpr (kFlat) {                                          // open the leaf (src/BIH.hs:105): Nothing so far -- as selects
+                const bool open = T.mode == M_LEAF;                         // (a resident leaf reference decodes without a load)
+                const int2 lf = G.leaf(T.cur);
+                lf_first = open ? lf.x : lf_first; lf_cnt = open ? lf.y : lf_cnt; T.R.tri = open ? -1 : T.R.tri;
+                T.mode = open ? (lf.y > 0 ? M_LEAFQ : M_UNWIND) : T.mode;
+            } else
             if (T.mode == M_LEAF) {                                         // open the leaf (src/BIH.hs:105): Nothing so far
                 const int2 lf = G.leaf(T.cur);
                 lf_first = lf.x; lf_cnt = lf.y; T.R.tri = -1;
@@ -876,6 +882,11 @@ __device__ __forceinline__ void trace_rays_body(const SceneView& S, const TraceA
                 }
                 const int done = min(U, nwin << 6);                             // units tested
                 if (PROFILE) { pf_leaf += nwin; pf_outer += NT * done; }
+                if constexpr (kFlat) {
+                    const bool fin = u > 0 && incl <= done;                     // the Leaf equation is finished: R is its value
+                    const int adv = (u > 0 && incl > done && start < done) ? NT * (done - start) : 0;   // whole units come first
+                    T.mode = fin ? M_UNWIND : T.mode; lf_first += adv; lf_cnt -= adv;
+                } else
                 if (u > 0) {
                     if (incl <= done) T.mode = M_UNWIND;                        // the Leaf equation is finished: R is its value
                     else if (start < done) { lf_first += NT * (done - start); lf_cnt -= NT * (done - start); }   // whole units come first
