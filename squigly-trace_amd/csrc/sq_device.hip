@@ -733,7 +733,8 @@ __device__ __forceinline__ void trace_rays_body(const SceneView& S, const TraceA
         // leaf order, with the very comparison of the one-lane leaf loop (minimumBy's rule, src/BIH.hs:105-109) --
         // the arithmetic of mollerTrumbore does not depend on the lane that runs it.
         constexpr int KW = kPoolWindows;
-        constexpr bool kFlat = RESIDENT && !PROFILE && (SQ_FLAT_STEPS != 0) && (SQ_DESCEND_PREFETCH == 0) && !ResidentNodes::kBoxInRegisters && !ResidentNodes::kIncremental;
+        constexpr bool kFlat = (RESIDENT ? !ResidentNodes::kBoxInRegisters && !ResidentNodes::kIncremental : (SQ_FLAT_STREAM != 0) && (SQ_STREAM_CULL16 != 0) && !HybridNodes::kBoxInRegisters)
+                               && !PROFILE && (SQ_FLAT_STEPS != 0) && (SQ_DESCEND_PREFETCH == 0);
         bool flat_ok = false;               // wave-uniform (kFlat): every ray of the wave is safe and the scene has culling boxes
         SQ_LDS uint8_t* tab = to_lds<uint8_t>(lds + L.tab) + (threadIdx.x >> 6) * (64 * KW);   // this wave's window-head tables
         for (int k = 0; k < KW; ++k) tab[k * 64 + lane] = 0;
@@ -782,7 +783,7 @@ __device__ __forceinline__ void trace_rays_body(const SceneView& S, const TraceA
                     const uint32_t e = stk[T.sp * BLOCK];                       // (slot 0, unused, for a ray that is done)
                     const bool is_combine = !done && (e & flag) != 0, is_far = !done && (e & flag) == 0;
                     if (is_combine) trav_unwind_combine<TriSrc, StackT>(T, G, e);
-                    if (is_far) trav_unwind_far_flat<StackT>(T, N, stk, BLOCK, e);
+                    if (is_far) trav_unwind_far_flat<NodeSrc, StackT>(T, N, stk, BLOCK, e);
                     T.mode = done ? M_DONE : T.mode;
                 }
             } else
@@ -790,7 +791,7 @@ __device__ __forceinline__ void trace_rays_body(const SceneView& S, const TraceA
             stamp(1);
             if (PROFILE) pl_desc += (T.mode == M_DESCEND);
             if constexpr (kFlat) {
-                if (T.mode == M_DESCEND) { if (flat_ok) trav_descend_flat<StackT>(T, N, stk, BLOCK); else trav_descend(T, N, stk, BLOCK, &pf); }
+                if (T.mode == M_DESCEND) { if (flat_ok) trav_descend_flat<NodeSrc, StackT>(T, N, stk, BLOCK); else trav_descend(T, N, stk, BLOCK, &pf); }
             } else
             if (T.mode == M_DESCEND) trav_descend(T, N, stk, BLOCK, &pf);
             // With the culling boxes a ray takes four branch steps per leaf it opens: lanes that are still descending take up
@@ -800,7 +801,7 @@ __device__ __forceinline__ void trace_rays_body(const SceneView& S, const TraceA
                 if (__popcll(sq_ballot(T.mode == M_DESCEND)) < A.descend_lanes) break;
                 if (PROFILE) pl_desc += (T.mode == M_DESCEND);
                 if constexpr (kFlat) {
-                    if (T.mode == M_DESCEND) { if (flat_ok) trav_descend_flat<StackT>(T, N, stk, BLOCK); else trav_descend(T, N, stk, BLOCK, &pf); }
+                    if (T.mode == M_DESCEND) { if (flat_ok) trav_descend_flat<NodeSrc, StackT>(T, N, stk, BLOCK); else trav_descend(T, N, stk, BLOCK, &pf); }
                 } else
                 if (T.mode == M_DESCEND) trav_descend(T, N, stk, BLOCK, &pf);
             }
@@ -808,7 +809,7 @@ __device__ __forceinline__ void trace_rays_body(const SceneView& S, const TraceA
 #ifdef SQ_SETPRIO      // ... and in its leaf scan and pair windows (bits 3..2)
             __builtin_amdgcn_s_setprio((SQ_SETPRIO >> 2) & 3);
 #endif
-            if constexpr (kFlat) {                                          // open the leaf (src/BIH.hs:105): Nothing so far -- as selects
+            if constexpr (kFlat && RESIDENT) {                              // open the leaf (src/BIH.hs:105): Nothing so far -- as selects
                 const bool open = T.mode == M_LEAF;                         // (a resident leaf reference decodes without a load)
                 const int2 lf = G.leaf(T.cur);
                 lf_first = open ? lf.x : lf_first; lf_cnt = open ? lf.y : lf_cnt; T.R.tri = open ? -1 : T.R.tri;

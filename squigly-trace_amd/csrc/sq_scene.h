@@ -984,9 +984,12 @@ __device__ __forceinline__ void trav_unwind(Trav& T, const NodeSrc& N, const Tri
 #ifndef SQ_FLAT_STEPS
 #define SQ_FLAT_STEPS 1
 #endif
-template <typename StackT>
-__device__ __forceinline__ void trav_descend_flat(Trav& T, const ResidentNodes& N, SQ_LDS StackT* stk, int stride) {
-    const ResidentNodes::CullBoxes cb = N.cull_load(T.cur);             // both children's culling boxes, requested first
+#ifndef SQ_FLAT_STREAM
+#define SQ_FLAT_STREAM 0          // the same steps in the streaming form's pooled kernel (HybridNodes): A/B switch
+#endif
+template <typename NodeSrc, typename StackT>
+__device__ __forceinline__ void trav_descend_flat(Trav& T, const NodeSrc& N, SQ_LDS StackT* stk, int stride) {
+    const typename NodeSrc::CullBoxes cb = N.cull_load(T.cur);          // both children's culling boxes, requested first
     const BranchData B = N.load(T.cur);
     const v4f q0 = B.q0, q1 = B.q1; const int ax = B.axis;
     const float lmax = q0.w, rmin = q1.w;
@@ -1012,8 +1015,8 @@ __device__ __forceinline__ void trav_descend_flat(Trav& T, const ResidentNodes& 
 }
 // The FAR half of a return (the popped frame is a branch whose near child returned R).  Pre: mode == M_UNWIND, the popped word `e`
 // has no COMBINE flag; T.sp already points at the popped frame.
-template <typename StackT>
-__device__ __forceinline__ void trav_unwind_far_flat(Trav& T, const ResidentNodes& N, SQ_LDS StackT* stk, int stride, uint32_t e) {
+template <typename NodeSrc, typename StackT>
+__device__ __forceinline__ void trav_unwind_far_flat(Trav& T, const NodeSrc& N, SQ_LDS StackT* stk, int stride, uint32_t e) {
     constexpr uint32_t flag = StackTraits<StackT>::flag;
     const BranchTail B = N.tail(e);
     const int ax = B.axis;
