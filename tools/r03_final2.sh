@@ -10,4 +10,4 @@ timeout -k 10 $((FZ + 120)) python tests/fuzz_gpu.py $FZ 40000000 2>&1 | grep -v
 timeout -k 10 $((FZ + 180)) python tests/fuzz_gpu.py $FZ 41000000 big 2>&1 | grep -v amdgpu | tail -2 | tee -a $O/${TAG}_fuzz.log
 timeout -k 10 1000 python tools/collect_profiles.py $TAG headline c3 c5 > $O/${TAG}_collect.log 2>&1; echo "collect rc=$?"
 cp $O/profiles_$TAG/latest_pmc.json profiles/latest_pmc.json; cp $O/profiles_$TAG/latest_other_configs.json profiles/latest_other_configs.json
-timeout -k 10 600 python bench.py --steps 20 --warmup 5 > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err; echo "bench rc=$?"; cut -c1-200 $O/${TAG}_bench.json
+SECONDS=0; timeout -k 10 600 python bench.py --steps 20 --warmup 5 > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err; echo "bench rc=$? in ${SECONDS} s"; cut -c1-200 $O/${TAG}_bench.json
