@@ -10,6 +10,6 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun
 f=$(ls gpurun_out/kt_$TAG/*/*kernel_stats.csv | head -1)
 echo "== $TAG ($LIB) $*"; python - "$f" <<'PY'
 import csv,sys
-for r in list(csv.DictReader(open(sys.argv[1])))[:6]:
+for r in list(csv.DictReader(open(sys.argv[1])))[:14]:
     if 'sq_' in r['Name']: print(f"  {r['Name'][:44]:46s} calls {r['Calls']:>3s} avg {float(r['AverageNs'])/1e3:9.1f} us")
 PY
