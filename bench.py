@@ -426,7 +426,8 @@ def main():
             dt = time.perf_counter() - t1
             out["one_shot_call"] = {"ms": round(dt * 1e3, 2), "msamples_per_s": round(samples_per_step / dt / 1e6, 1),
                                     "what": "sq_render_rgb8: scene upload + render + 6.2 MB copy back, host buffers in and out"}
-        if single and not args.no_oneshot and args.config == "c2" and not (args.width or args.height or args.spp):
+        if single and with_other and not args.no_oneshot and args.config == "c2" and not (args.width or args.height or args.spp):
+            # (not in --no-other runs: those are the profiling commands, whose per-kernel averages must stay those of the serial schedule)
             # The same frames with the library's two-pipeline schedule (option overlap = 2: even and odd sample batches on two
             # streams, one pipeline's launches filling the other's ramp-downs and per-sample kernels).  Same image bit for bit.
             # Reported beside `value`, not as it: `value` and the roofline are measured on the serial schedule, where a launch

@@ -142,6 +142,8 @@ int  sq_get_stats(sq_device_scene* s, uint64_t* out, int32_t n, int32_t reset);
  *   "cull"               1 (default): a ray inside the limits of sq_cull_boxes (squigly_host.h) that misses a leaf's culling box
  *                        skips the leaf's triangle tests -- the reference's mollerTrumbore would reject them all, so no bit
  *                        changes; 0: every leaf the reference visits is tested
+ *   "primary_tiles"      1 (default): the primary rays of a shard are enumerated in tiles (8 x 8 pixels on a whole image, 2 x 32 with
+ *                        row blocks of 2) so that the 64 rays of a wave stay together in both image directions; 0: 64 pixels of a row
  *   "incremental"        only in builds with -DSQ_RES_INCREMENTAL=1 (measured and rejected): the resident form carries
  *                        (tmin, tmax) of the reference's slab test down the tree instead of testing both children from scratch */
 int  sq_set_option(sq_device_scene* s, const char* key, int64_t value);

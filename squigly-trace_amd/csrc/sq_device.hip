@@ -86,6 +86,7 @@ struct Frame {
     float cam_pos[3]; float cam_rot[9];
     int32_t samples, w, h, cast;
     int32_t row_block, shard, n_shards, local_rows;
+    int32_t tile_rows, tiles_x;   // primary rays are enumerated in tiles of tile_rows x (64 / tile_rows) pixels (primary_tile), tiles_x per tile row
     float* out_avg; uint8_t* out_rgb;
     int32_t diag;             // option "coresidency": the per-sample kernels and the trace kernel count who runs beside whom (sq_get_stats 24..27)
 };
@@ -94,6 +95,21 @@ __device__ __forceinline__ void pixel_coords(const Frame& F, int pix, int& y, in
     x = pix - j * F.h;
     const int blk = j / F.row_block;
     y = (blk * F.n_shards + F.shard) * F.row_block + (j - blk * F.row_block);
+}
+// The q-th primary ray of a shard, q in [0, primary_padded(F)): a wave takes a TILE of tile_rows x (64 / tile_rows) neighbouring pixels
+// instead of 64 pixels of one row, so that the 64 rays of a one-ray-per-lane walk -- which runs the UNION of their paths -- stay together
+// in both image directions (tile_rows adjacent local rows are adjacent image rows: it divides row_block, or the shard is the whole image).
+// Returns the pixel's row-major local index (what px_pixel holds and everything downstream uses), or -1 for the padding of edge tiles.
+__device__ __forceinline__ long long primary_tile(const Frame& F, long long q) {
+    const int lane = (int)(q & 63), tw = 64 / F.tile_rows;
+    const long long tile = q >> 6;
+    const long long ty = tile / F.tiles_x; const int tx = (int)(tile - ty * F.tiles_x);
+    const int jj = lane / tw, xx = lane - jj * tw;
+    const long long j = ty * F.tile_rows + jj; const int x = tx * tw + xx;
+    return (j < F.local_rows && x < F.h) ? j * F.h + x : -1;
+}
+__host__ __device__ __forceinline__ long long primary_padded(const Frame& F) {
+    return (long long)((F.local_rows + F.tile_rows - 1) / F.tile_rows) * F.tiles_x * 64;
 }
 __device__ __forceinline__ void pixel_coords(const Frame& F, long long pix, int& y, int& x) {
     const int j = (int)(pix / F.h);
@@ -219,8 +235,9 @@ template <typename StackT>
 __global__ void __launch_bounds__(kBlock) sq_primary(const SceneView S, const Frame F, const Work W) {
     extern __shared__ float4 lds_raw[];
     SQ_LDS StackT* stk = to_lds<StackT>(lds_raw) + threadIdx.x;
-    const long long pix = (long long)blockIdx.x * kBlock + threadIdx.x;
-    const bool in = pix < (long long)F.local_rows * F.h;
+    const long long q = (long long)blockIdx.x * kBlock + threadIdx.x;
+    const long long pix = q < primary_padded(F) ? primary_tile(F, q) : -1;
+    const bool in = pix >= 0;
     Hit h0; h0.tri = -1; h0.t = 0;
     if (in) {
         int y, x; pixel_coords(F, pix, y, x);
@@ -609,10 +626,10 @@ __global__ void __launch_bounds__(kResidentBlock) sq_primary_resident(const Scen
     ResidentNodes N; ResidentTris G;
     stage_resident_scene<kResidentBlock>(S, S.n_branches, lds, L, N, G);
     __syncthreads();
-    const long long total = (long long)F.local_rows * F.h;
+    const long long total = primary_padded(F);
     for (long long base = (long long)blockIdx.x * kResidentBlock; base < total; base += (long long)gridDim.x * kResidentBlock) {
-        const long long pix = base + threadIdx.x;
-        const bool in = pix < total;
+        const long long pix = primary_tile(F, base + threadIdx.x);          // (total is a multiple of 64: whole waves)
+        const bool in = pix >= 0;
         Hit h0; h0.tri = -1; h0.t = 0;
         if (in) {
             int y, x; pixel_coords(F, pix, y, x);
@@ -1096,7 +1113,7 @@ struct sq_device_scene {
     // second stream of the overlapped schedule (launch_frame) and its event pool
     hipStream_t aux = nullptr; std::vector<hipEvent_t> events;
     int64_t opt_overlap = 0, opt_aux_blocks_per_cu = 0;
-    int64_t opt_pool = 1, opt_refill_min = 12, opt_flush_min = 40, opt_guided = 1, opt_primary_resident = 1, opt_pixel_major = -1, opt_cull = 1, opt_descend_extra = 2, opt_descend_lanes = 16, opt_primary_pooled = 0, opt_coresidency = 0, opt_trace_prio = 0, opt_aux_low_priority = 1, opt_aux_polite = 0, opt_incremental = 1;
+    int64_t opt_pool = 1, opt_refill_min = 12, opt_flush_min = 40, opt_guided = 1, opt_primary_resident = 1, opt_pixel_major = -1, opt_cull = 1, opt_descend_extra = 2, opt_descend_lanes = 16, opt_primary_pooled = 0, opt_coresidency = 0, opt_trace_prio = 0, opt_aux_low_priority = 1, opt_aux_polite = 0, opt_incremental = 1, opt_primary_tiles = 1;
 };
 
 namespace {
@@ -1648,11 +1665,11 @@ int launch_frame(sq_device_scene* s, const Frame& F, hipStream_t stream) {
     } else if (resident && s->opt_primary_resident) {
         const TraceLds Lp = trace_lds_layout(S.n_branches, true, S.n_verts, S.n_tris, kResidentBlock, stack_cap, (int)sizeof(StackT), false);
         SQ_HIP(hipFuncSetAttribute((const void*)sq_primary_resident<StackT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Lp.total));
-        const long long need = (pixels + kResidentBlock - 1) / kResidentBlock;
+        const long long need = (primary_padded(F) + kResidentBlock - 1) / kResidentBlock;
         hipLaunchKernelGGL(sq_primary_resident<StackT>, dim3((unsigned)std::min<long long>(s->n_cu, need)), dim3(kResidentBlock), Lp.total, stream, S, F, W, stack_cap);
     } else {
         if (px_lds > 64 * 1024) SQ_HIP(hipFuncSetAttribute((const void*)sq_primary<StackT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)px_lds));
-        hipLaunchKernelGGL(sq_primary<StackT>, dim3((unsigned)px_blocks), dim3(kBlock), px_lds, stream, S, F, W);
+        hipLaunchKernelGGL(sq_primary<StackT>, dim3((unsigned)((primary_padded(F) + kBlock - 1) / kBlock)), dim3(kBlock), px_lds, stream, S, F, W);
     }
     SQ_HIP(hipGetLastError());
     const int aux_blocks = s->n_cu * (int)(s->opt_aux_blocks_per_cu ? s->opt_aux_blocks_per_cu : 8);
@@ -1853,6 +1870,13 @@ extern "C" int sq_render_rows_device(sq_device_scene* s, const sq_camera* cam, i
     std::memcpy(F.cam_rot, cam->rot, sizeof F.cam_rot);
     F.samples = samples; F.w = w; F.h = h; F.cast = cast ? 1 : 0;
     F.row_block = sh.row_block; F.shard = sh.shard; F.n_shards = sh.n_shards; F.local_rows = rows;
+    {   // primary-ray tiles: as tall as the adjacency of local rows allows (8 x 8 on a whole image, 2 x 32 with blocks of 2 rows)
+        const int rb = sh.n_shards <= 1 ? 8 : sh.row_block;
+        F.tile_rows = rb >= 8 && rb % 8 == 0 ? 8 : rb >= 4 && rb % 4 == 0 ? 4 : rb >= 2 && rb % 2 == 0 ? 2 : 1;
+        if (s->opt_primary_tiles == 0) F.tile_rows = 1;
+        const int tw = 64 / F.tile_rows;
+        F.tiles_x = (h + tw - 1) / tw;
+    }
     F.out_avg = d_avg; F.out_rgb = d_rgb;
     F.diag = s->opt_coresidency ? std::max(1, s->n_cu - 8) : 0;   // "beside" = while all but a handful of the CUs hold a live trace workgroup
     hipStream_t stream = (hipStream_t)hip_stream;
@@ -1906,6 +1930,7 @@ extern "C" int sq_set_option(sq_device_scene* s, const char* key, int64_t value)
     if (!std::strcmp(key, "primary_resident")) { s->opt_primary_resident = value ? 1 : 0; return 0; }
     if (!std::strcmp(key, "cull")) { s->opt_cull = value ? 1 : 0; return 0; }
     if (!std::strcmp(key, "incremental")) { s->opt_incremental = value ? 1 : 0; return 0; }
+    if (!std::strcmp(key, "primary_tiles")) { s->opt_primary_tiles = value ? 1 : 0; return 0; }
     if (!std::strcmp(key, "primary_pooled")) { s->opt_primary_pooled = value != 0; return 0; }
     if (!std::strcmp(key, "coresidency")) { s->opt_coresidency = value != 0; return 0; }
     if (!std::strcmp(key, "aux_polite")) { if (value < 0 || value > 8) return sq_set_error("aux_polite must be in 0..8"); s->opt_aux_polite = value; return 0; }
