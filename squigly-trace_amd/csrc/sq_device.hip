@@ -546,7 +546,7 @@ __host__ __device__ inline TraceLds trace_lds_layout(int n_lds, bool resident, i
     auto al = [](uint32_t b) { return (b + 15u) & ~15u; };
     TraceLds L; uint32_t off = 0;
     L.verts = off; off += resident ? al((uint32_t)n_verts * 16u) : 0u;     // first: a vertex's LDS address is its byte offset (ResidentTris)
-    L.quads = off; off += al((uint32_t)n_lds * (resident ? 32u : 16u * HybridNodes::kLdsQuads));   // resident: 2 quads per branch; streaming: 3, or 5 with the culling boxes
+    L.quads = off; off += al((uint32_t)n_lds * (resident ? 32u : 48u));   // resident: 2 quads per branch; streaming: 3
     L.refs = off;  off += resident ? al((uint32_t)n_lds * 8u) : 0u;
     L.trix = off;  off += resident ? al((uint32_t)(n_tris + ResidentTris::kRunPad) * 8u) : 0u;  // + zero records: get_run may read past the last triangle
     L.live = off;  off += al((uint32_t)(block / 64) * (uint32_t)(resident ? kChunkResident : kChunkStreaming) * (uint32_t)sizeof(LiveT));
@@ -660,10 +660,7 @@ __device__ __forceinline__ void trace_rays_body(const SceneView& S, const TraceA
         stage_resident_scene<BLOCK>(S, A.n_lds, lds, L, N, G);
         root_ref = S.rroot;
     } else {
-        {   // the top of the tree (a prefix of the breadth-first tables), with its culling boxes when the records are the merged ones
-            const float4* src = HybridNodes::kLdsQuads == 5u ? S.branches_m : S.branches;
-            for (int i = threadIdx.x; i < (int)HybridNodes::kLdsQuads * A.n_lds; i += BLOCK) { const float4 q = src[i]; lquads[i] = v4f{ q.x, q.y, q.z, q.w }; }
-        }
+        for (int i = threadIdx.x; i < 3 * A.n_lds; i += BLOCK) { const float4 q = S.branches[i]; lquads[i] = v4f{ q.x, q.y, q.z, q.w }; }
 #if SQ_STREAM_CULL16
         N = HybridNodes{ lquads, HybridNodes::kMerged ? S.branches_m : S.branches, (uint32_t)A.n_lds, S.cull_child != nullptr, S.cull_child16 };
 #else
@@ -1618,19 +1615,18 @@ int launch_frame(sq_device_scene* s, const Frame& F, hipStream_t stream) {
         trace_blocks = s->n_cu; trace_threads = kResidentBlock;
     } else {
         const size_t max_node_bytes = (size_t)s->opt_lds_node_kb * 1024;     // top of the tree; the rest of LDS buys occupancy
-        constexpr size_t kNodeBytes = 16u * HybridNodes::kLdsQuads;     // of the LDS copy of a branch
-        const int n_lds_want = (int)std::min<size_t>((size_t)S.n_branches, max_node_bytes / kNodeBytes);
+        const int n_lds_want = (int)std::min<size_t>((size_t)S.n_branches, max_node_bytes / 48);
         const TraceLds L0 = trace_lds_layout(0, false, S.n_verts, S.n_tris, kTraceBlock, stack_cap, (int)sizeof(StackT), pool);   // stacks, live lists, window tables
         if (L0.total > lds_budget) return sq_set_error("BIH height %d needs %u B of LDS per workgroup (max %zu)", S.height, L0.total, lds_budget);
         // Three workgroups per CU (the six-wave build) when a third of the LDS holds a workgroup's stacks plus at least 4 KB of
         // the tree's top (or all of it); otherwise two, or one, with up to lds_node_kb of tree each.
         const size_t third = (lds_budget / 3) & ~(size_t)2047;            // 52 KB: the hardware allocates LDS in granules, and 3 x 53.3 KB rounded up does not fit
-        const bool dense_fits = L0.total + std::min<size_t>((size_t)S.n_branches * kNodeBytes, 4096) + 16 <= third;
+        const bool dense_fits = L0.total + std::min<size_t>((size_t)S.n_branches * 48, 4096) + 16 <= third;
         const bool dense = pool && !s->opt_profile && (s->opt_trace_blocks_per_cu == 0 ? dense_fits : s->opt_trace_blocks_per_cu == 3 && dense_fits);
         int per_cu;
         if (dense) {
             per_cu = 3;
-            n_lds = (int)std::min<size_t>((size_t)n_lds_want, (third - L0.total - 16) / kNodeBytes);
+            n_lds = (int)std::min<size_t>((size_t)n_lds_want, (third - L0.total - 16) / 48);
         } else {
             n_lds = n_lds_want;
             while (n_lds > 0 && trace_lds_layout(n_lds, false, S.n_verts, S.n_tris, kTraceBlock, stack_cap, (int)sizeof(StackT), pool).total > lds_budget) n_lds /= 2;

@@ -389,25 +389,12 @@ struct HybridNodes {            // first n_lds branches (top of the tree) in LDS
 #endif
     static constexpr bool kMerged = (SQ_STREAM_MERGED != 0) && (SQ_STREAM_CULL16 != 0);
     static constexpr uint32_t kStride = kMerged ? 5u : 3u;      // quads per record in `g`
-    // SQ_STREAM_LDS_CULL (needs kMerged): the LDS copy of the tree's top holds the whole 80-byte records, culling boxes included, so that
-    // a visit of one of those branches issues no vector-memory load at all (the L1 spends a tag lookup per lane and load instruction,
-    // and the 82k-triangle scene keeps the TA 69 % busy with them: profiles/r03zz_pmc_mem_c3.txt); fewer branches fit (80 instead of 48 bytes)
-#ifndef SQ_STREAM_LDS_CULL
-#define SQ_STREAM_LDS_CULL 1
-#endif
-    static constexpr uint32_t kLdsQuads = (kMerged && (SQ_STREAM_LDS_CULL != 0)) ? 5u : 3u;    // quads per branch in the LDS copy `l`
     const SQ_LDS v4f* l; const float4* g; uint32_t n_lds;      // g = SceneView::branches_m (kMerged) or SceneView::branches
     bool cull_on;
 #if SQ_STREAM_CULL16
     const uint4* cull16;                                       // !kMerged: the culling boxes' own table
     struct CullBoxes { uint4 l, r; };
     __device__ __forceinline__ CullBoxes cull_load(uint32_t parent) const {
-        if constexpr (kLdsQuads == 5u) {
-            if (parent < n_lds) {
-                const v4f a = l[5 * parent + 3], c = l[5 * parent + 4];
-                return CullBoxes{ uint4{ __float_as_uint(a.x), __float_as_uint(a.y), __float_as_uint(a.z), __float_as_uint(a.w) }, uint4{ __float_as_uint(c.x), __float_as_uint(c.y), __float_as_uint(c.z), __float_as_uint(c.w) } };
-            }
-        }
         if constexpr (kMerged) {
             const float4* p = g + (size_t)parent * kStride;
             const float4 a = p[3], c = p[4];
@@ -425,13 +412,13 @@ struct HybridNodes {            // first n_lds branches (top of the tree) in LDS
     __device__ __forceinline__ bool cull_test(const CullBoxes& c, bool left, f3 df, f3 nodf) const { return cull_test32(c, left, df, nodf); }
 #endif
     __device__ __forceinline__ BranchData load(uint32_t b) const {
-        if (b < n_lds) return unpack_branch(l[kLdsQuads * b], l[kLdsQuads * b + 1], l[kLdsQuads * b + 2]);
+        if (b < n_lds) return unpack_branch(l[3 * b], l[3 * b + 1], l[3 * b + 2]);
         const float4* p = g + (size_t)b * kStride;
         const float4 a = p[0], c = p[1], d = p[2];
         return unpack_branch(v4f{ a.x, a.y, a.z, a.w }, v4f{ c.x, c.y, c.z, c.w }, v4f{ d.x, d.y, d.z, d.w });
     }
     __device__ __forceinline__ BranchTail tail(uint32_t b) const {
-        if (b < n_lds) return unpack_tail(l[kLdsQuads * b + 2]);
+        if (b < n_lds) return unpack_tail(l[3 * b + 2]);
         const float4 d = g[(size_t)b * kStride + 2];
         return unpack_tail(v4f{ d.x, d.y, d.z, d.w });
     }
