@@ -62,6 +62,14 @@ constexpr int kChunkResident = 512, kChunkStreaming = 128;
 using LiveT = uint8_t;             // a live slot's index within its chunk
 #ifndef SQ_POOL_KW
 #define SQ_POOL_KW 1
+// Instruction-arbitration priority of a trace wave (s_setprio): bits 1..0 in its return / branch steps, bits 3..2 in its leaf scan and pair
+// windows (and the store / refill that follows them).  4 = priority 1 in the windows, 0 in the steps: with the flat steps the headline
+// frame takes 52.4-52.5 ms instead of 53.3-53.4 (levels 1, 2 and 3 alike; raising the STEPS instead costs 0.5 ms), one rank's share at
+// 8 ranks 8.09 -> 7.98 ms, the streaming form +-0 (profiles/r03zz5_setprio_flat.txt, r03zz6_setprio_stream.txt).  Round 2 had measured
+// -0.5 % for the same setting on the kernels of its time and left it off.  -DSQ_SETPRIO=0 builds without it.
+#ifndef SQ_SETPRIO
+#define SQ_SETPRIO 4
+#endif
 #endif
 constexpr int kStatSlots = 32;            // sq_get_stats
 #ifndef SQ_STAGE_BATCHED
@@ -528,7 +536,8 @@ struct TraceArgs {
     int32_t flush_min;           // pooled form: a trailing part-filled window of the pair pool is run at once from this many pairs on
     int32_t descend_extra, descend_lanes;   // pooled form: further branch steps per iteration for lanes that keep descending, and how many such lanes it takes
     int32_t diag;                // option "coresidency": keep the gauge of live workgroups in stats[24]
-    int32_t prio;                // option "trace_prio": s_setprio level of the trace kernel's waves (0 = leave it), for the overlapped
+    int32_t prio;                // option "trace_prio": s_setprio level of the trace kernel's waves when they start (0 = leave it; the pooled
+                                 //   kernel then sets its own levels per phase, SQ_SETPRIO, so it only lasts in pool = 0 launches), for the overlapped
                                  //   schedules: per-sample kernels that share a SIMD with a trace workgroup then only get the issue
                                  //   slots the trace waves leave free
     int32_t pixel_major;         // queue ORDER: 0 = slot order (sample-major: neighbouring pixels, one sample each), 1 = all samples
@@ -786,7 +795,7 @@ __device__ __forceinline__ void trace_rays_body(const SceneView& S, const TraceA
                   asm volatile("v_add_u32 %0, %0, %1" : "+v"(x2) : "v"(lane)); asm volatile("v_add_u32 %0, %0, %1" : "+v"(x3) : "v"(lane)); }
               asm volatile("" :: "v"(x0), "v"(x1), "v"(x2), "v"(x3)); }
 #endif
-#ifdef SQ_SETPRIO      // timing experiment (results unchanged): instruction-arbitration priority of a wave in its return / branch steps
+#if SQ_SETPRIO         // instruction-arbitration priority of a wave in its return / branch steps (results unchanged)
             __builtin_amdgcn_s_setprio(SQ_SETPRIO & 3);
 #endif
             if (PROFILE) pl_unw += (T.mode == M_UNWIND);
@@ -823,7 +832,7 @@ __device__ __forceinline__ void trace_rays_body(const SceneView& S, const TraceA
                 if (T.mode == M_DESCEND) trav_descend(T, N, stk, BLOCK, &pf);
             }
             stamp(2);
-#ifdef SQ_SETPRIO      // ... and in its leaf scan and pair windows (bits 3..2)
+#if SQ_SETPRIO         // ... and in its leaf scan and pair windows (bits 3..2)
             __builtin_amdgcn_s_setprio((SQ_SETPRIO >> 2) & 3);
 #endif
             if constexpr (kFlat && RESIDENT) {                              // open the leaf (src/BIH.hs:105): Nothing so far -- as selects
